@@ -1,0 +1,202 @@
+/*
+ * orbslam_amd.h -- C-ABI of the MI355X (gfx950) hot path of Sunny-cpp/orbslam_In_practice.
+ *
+ * Plain C, POD only: no cv::, STL, Eigen or torch types cross this boundary.  The thin C++ classes in
+ * include/orbslam_amd/{ORBextractor,ORBmatcher,Optimizer}.h keep the reference's own call signatures
+ * and forward to these entry points.
+ *
+ * Every function returns 0 on success or a negative ORB_E_* code; all output buffers are caller
+ * allocated.  A handle owns its device memory, pinned staging and one HIP stream; use one handle per
+ * host thread (the reference's ORBextractor is likewise non re-entrant: include/ORBextractor.h:71).
+ *
+ * There is NO CPU fallback: if no HIP device is usable, create() fails with ORB_E_NO_DEVICE.
+ */
+#ifndef ORBSLAM_AMD_H
+#define ORBSLAM_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    ORB_OK = 0,
+    ORB_E_INVALID = -1,   /* bad argument (null pointer, non-positive size, unsupported config)        */
+    ORB_E_CAPACITY = -2,  /* caller's output capacity too small / batch larger than the handle's max  */
+    ORB_E_NO_DEVICE = -3, /* no usable HIP device                                                      */
+    ORB_E_HIP = -4,       /* a HIP runtime call failed (orb_last_error() has the text)                 */
+    ORB_E_ASPECT = -5,    /* image so tall that the reference's quadtree root count rounds to 0 (the
+                             reference divides by zero there, src/ORBextractor.cpp:493-495)           */
+    ORB_E_STOPPED = -6,   /* ba_solve: *stop became true before the first iteration                    */
+    ORB_E_SINGULAR = -7   /* ba_solve: linear system could not be solved at any damping               */
+};
+
+const char *orb_last_error(void);
+/* number of HIP devices visible (0 if none); never fails */
+int orb_device_count(void);
+
+/* cv::KeyPoint as a 28-byte POD: pt.x, pt.y, size, angle, response, octave, class_id */
+typedef struct OrbKeyPoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} OrbKeyPoint;
+
+/* ctor arguments of ORBSlam::ORBextractor (reference include/ORBextractor.h:35-36) */
+typedef struct OrbConfig {
+    int32_t nfeatures;
+    float scale_factor;
+    int32_t nlevels;
+    int32_t ini_th_fast;
+    int32_t min_th_fast;
+} OrbConfig;
+
+typedef struct OrbExtractor OrbExtractor; /* opaque */
+
+/* ---- ORBextractor (replaces reference src/ORBextractor.cpp:360-420 ctor) ----------------------
+ * max_w/max_h/max_batch size the device buffers (any smaller frame / batch is accepted later). */
+int orb_create(const OrbConfig *cfg, int max_w, int max_h, int max_batch, int device_id, OrbExtractor **out);
+void orb_destroy(OrbExtractor *h);
+
+/* the six getters of include/ORBextractor.h:47-69 plus mnFeaturesPerLevel / umax (a1) */
+int orb_get_levels(const OrbExtractor *h);
+float orb_get_scale_factor(const OrbExtractor *h);
+int orb_get_tables(const OrbExtractor *h, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2,
+                   int32_t *features_per_level, int32_t *umax16);
+/* pyramid level sizes for a w x h input (src/ORBextractor.cpp:1075-1077) */
+int orb_get_level_sizes(const OrbExtractor *h, int w, int hgt, int32_t *ws, int32_t *hs);
+/* worst-case number of keypoints one frame can return (sum over levels of quota + slack) */
+int orb_max_keypoints(const OrbExtractor *h);
+
+/* ---- ORBextractor::operator() (replaces src/ORBextractor.cpp:1001-1065) -------------------------
+ * gray: 8-bit single channel, `stride` bytes per row.  kps_out[cap], desc_out[cap*32].  An empty
+ * image (w<=0||h<=0||gray==NULL) returns ORB_OK with *n_out = 0 and leaves the outputs untouched
+ * (reference :1004-1005). */
+int orb_extract(OrbExtractor *h, const uint8_t *gray, int w, int hgt, int stride, OrbKeyPoint *kps_out,
+                uint8_t *desc_out, int cap, int32_t *n_out);
+
+/* n_frames independent frames of one size (BASELINE config 4).  imgs[f] -> frame f (host memory);
+ * kps_out[n_frames*cap], desc_out[n_frames*cap*32], n_out[n_frames]. */
+int orb_extract_batch(OrbExtractor *h, const uint8_t *const *imgs, int n_frames, int w, int hgt, int stride,
+                      OrbKeyPoint *kps_out, uint8_t *desc_out, int cap, int32_t *n_out);
+
+/* Same, but every pointer is DEVICE memory (frames at d_imgs + f*frame_stride) and the work is only
+ * enqueued on `stream` (a hipStream_t, NULL = the handle's own stream); nothing is copied to the host.
+ * d_kps[n_frames*cap], d_desc[n_frames*cap*32], d_counts[n_frames]. */
+int orb_extract_batch_device(OrbExtractor *h, const uint8_t *d_imgs, int n_frames, int w, int hgt, int stride,
+                             int64_t frame_stride, OrbKeyPoint *d_kps, uint8_t *d_desc, int cap,
+                             int32_t *d_counts, void *stream);
+
+/* mvImagePyramid (public member, include/ORBextractor.h:71): level `level` of frame `frame` of the
+ * most recent extract call, WITH its 19-px BORDER_REFLECT_101 apron (src/ORBextractor.cpp:1078-1093).
+ * out must hold (w_l+38)*(h_l+38) bytes.  blurred!=0 returns the 7x7 sigma=2 blurred level without
+ * apron (w_l*h_l bytes) instead (src/ORBextractor.cpp:1045-1046). */
+int orb_download_level(OrbExtractor *h, int frame, int level, int blurred, uint8_t *out);
+/* FAST candidates of (frame, level) before the quadtree, in the reference's order
+ * (src/ORBextractor.cpp:745-786); returns the count through n_out even if cap is too small. */
+int orb_download_candidates(OrbExtractor *h, int frame, int level, OrbKeyPoint *out, int cap, int32_t *n_out);
+/* wait for everything enqueued on the handle's stream */
+int orb_synchronize(OrbExtractor *h);
+/* the handle's hipStream_t */
+void *orb_stream(OrbExtractor *h);
+
+/* ---- ORBmatcher ----------------------------------------------------------------------------------
+ * orb_descriptor_distance: ORBmatcher::DescriptorDistance (src/ORBmatcher.cpp:128-144), host-side. */
+int orb_descriptor_distance(const uint8_t *a, const uint8_t *b);
+/* ORBmatcher::ComputeThreeMaxima (src/ORBmatcher.cpp:147-188) on the 30 bin sizes, host-side. */
+void orb_compute_three_maxima(const int32_t *histo_sizes, int L, int32_t *ind1, int32_t *ind2, int32_t *ind3);
+
+typedef struct OrbMatcher OrbMatcher; /* opaque: device buffers + stream for matching */
+int orb_matcher_create(int max_keypoints, int max_pairs, int device_id, OrbMatcher **out);
+void orb_matcher_destroy(OrbMatcher *m);
+void *orb_matcher_stream(OrbMatcher *m);
+int orb_matcher_synchronize(OrbMatcher *m);
+
+/* brute-force Hamming 2-NN (north_star): for every row of d1[n1*32] the best and second
+ * best distance over all rows of d2[n2*32]; ties -> lowest index; second counts duplicates; n2==0
+ * gives idx=-1, best=second=0xFFFF.  Host pointers. */
+int orb_hamming_knn2(OrbMatcher *m, const uint8_t *d1, int n1, const uint8_t *d2, int n2, int32_t *idx,
+                     uint16_t *best, uint16_t *second);
+
+/* one frame as the matcher sees it (Frame::GetUnKeyPts / GetDescriptors / image bounds) */
+typedef struct OrbFrameView {
+    const OrbKeyPoint *kps; /* undistorted keypoints, n entries                  */
+    const uint8_t *desc;    /* n x 32 bytes                                       */
+    int32_t n;
+    float min_x, max_x, min_y, max_y; /* Frame::miMinX.. (src/Frame.cpp:111-141) */
+} OrbFrameView;
+
+/* ORBmatcher::SearchForInitialization (src/ORBmatcher.cpp:9-126) with Frame::GetFeaturesInArea
+ * (src/Frame.cpp:219-271).  prev_matched_xy[2*n1] in/out, matches12[n1] out (-1 = none); returns the
+ * number of matches through n_matches.  window_size < 0 selects the brute-force variant (every
+ * octave, every keypoint of F2 in ascending index order as candidates). */
+int orb_match_init(OrbMatcher *m, const OrbFrameView *f1, const OrbFrameView *f2, float *prev_matched_xy,
+                   int32_t *matches12, int window_size, float nnratio, int check_orientation,
+                   int32_t *n_matches);
+
+/* Batched, device-resident matching of n_pairs frame pairs (pair p: frame a[p] against frame b[p] of
+ * the slabs an extractor produced with capacity `cap`): d_kps[n_frames*cap], d_desc[n_frames*cap*32],
+ * d_counts[n_frames].  prev_matched is taken to be F1's own keypoint positions (first call of
+ * Tracking::MonocularInitialization, src/Tracking.cpp:170-189).  d_matches12[n_pairs*cap],
+ * d_nmatches[n_pairs].  Enqueued on `stream` (NULL = matcher's stream). */
+int orb_match_batch_device(OrbMatcher *m, const OrbKeyPoint *d_kps, const uint8_t *d_desc,
+                           const int32_t *d_counts, int cap, const int32_t *d_pair_a, const int32_t *d_pair_b,
+                           int n_pairs, float min_x, float max_x, float min_y, float max_y, int window_size,
+                           float nnratio, int check_orientation, int32_t *d_matches12, int32_t *d_nmatches,
+                           void *stream);
+
+/* ---- Optimizer -----------------------------------------------------------------------------------
+ * One bundle-adjustment problem in g2o's terms (reference src/Optimizer.cpp:23-129): SE3 pose
+ * vertices (qw,qx,qy,qz,tx,ty,tz; world->camera, the reference's "Rwc/twc"), XYZ point vertices
+ * (marginalised), one EdgeSE3ProjectXYZ per observation. */
+typedef struct BAProblem {
+    int32_t n_cams, n_points, n_obs;
+    const double *poses;      /* n_cams x 7                                              */
+    const uint8_t *fixed;     /* n_cams: 1 = vertex fixed (KF id 0, src/Optimizer.cpp:52) */
+    const double *points;     /* n_points x 3                                            */
+    const double *obs;        /* n_obs x 2 (undistorted keypoint)                        */
+    const int32_t *cam_idx;   /* n_obs                                                   */
+    const int32_t *pt_idx;    /* n_obs                                                   */
+    const double *inv_sigma2; /* n_obs: information = I * inv_sigma2                      */
+    double fx, fy, cx, cy;
+    double huber_delta;       /* <= 0: no robust kernel (bRobust=false)                   */
+    /* schedule: rounds[i] LM iterations; after round i (if i+1 < n_rounds) edges with chi2 >
+     * chi2_threshold or non-positive depth are switched off (level 1) and, if drop_robust_after == i,
+     * the robust kernel is removed from the rest.  GlobalBA: n_rounds=1, rounds={nIterations};
+     * LocalBA: n_rounds=2, rounds={5,10}, chi2_threshold=5.991, drop_robust_after=0. */
+    int32_t n_rounds;
+    int32_t rounds[4];
+    double chi2_threshold;
+    int32_t drop_robust_after;
+    volatile const uint8_t *stop; /* optional pbStopFlag, polled between iterations */
+} BAProblem;
+
+typedef struct BAResult {
+    double *poses;       /* n_cams x 7 out   */
+    double *points;      /* n_points x 3 out */
+    uint8_t *outlier;    /* n_obs out (1 = switched off), may be NULL */
+    double chi2_initial; /* robustified chi2 before / after */
+    double chi2_final;
+    int32_t iterations;  /* LM iterations actually run */
+    int32_t lin_solves;  /* linear systems solved (incl. rejected LM trials) */
+} BAResult;
+
+typedef struct BASolver BASolver; /* opaque */
+int ba_create(int max_cams, int max_points, int max_obs, int max_batch, int device_id, BASolver **out);
+void ba_destroy(BASolver *s);
+/* Optimizer::BundleAdjustment / LocalBundleAdjustment numerical core */
+int ba_solve(BASolver *s, const BAProblem *p, BAResult *r);
+/* n independent windows (BASELINE config 3 / target), solved concurrently on the device */
+int ba_solve_batch(BASolver *s, const BAProblem *p, BAResult *r, int n);
+
+/* Optimizer::PoseOptimization numerical core (src/Optimizer.cpp:131-261): one free pose, n unary
+ * edges with fixed Xw; 4 rounds x 10 iterations with chi2 relabelling; robust kernel dropped after
+ * round index 2.  pose[7] in/out, outlier[n] out; returns inliers through n_inliers. */
+int ba_pose_optimization(BASolver *s, double *pose, const double *xw, const double *obs,
+                         const double *inv_sigma2, int n, double fx, double fy, double cx, double cy,
+                         uint8_t *outlier, int32_t *n_inliers);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBSLAM_AMD_H */

@@ -1,0 +1,138 @@
+"""ctypes binding of the C-ABI (include/orbslam_amd.h) -> csrc/liborbslam_amd.so.
+
+Fails LOUDLY when the HIP library is missing: there is no CPU or PyTorch fallback in this package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "liborbslam_amd.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+ORB_OK, ORB_E_INVALID, ORB_E_CAPACITY, ORB_E_NO_DEVICE, ORB_E_HIP, ORB_E_ASPECT, ORB_E_STOPPED, ORB_E_SINGULAR = \
+    0, -1, -2, -3, -4, -5, -6, -7
+_ERR_NAMES = {-1: "ORB_E_INVALID", -2: "ORB_E_CAPACITY", -3: "ORB_E_NO_DEVICE", -4: "ORB_E_HIP",
+              -5: "ORB_E_ASPECT", -6: "ORB_E_STOPPED", -7: "ORB_E_SINGULAR"}
+
+
+class OrbError(RuntimeError):
+    def __init__(self, code, msg=""):
+        self.code = code
+        super().__init__("%s (%d) %s" % (_ERR_NAMES.get(code, "ORB_E_?"), code, msg))
+
+
+class OrbConfig(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
+
+
+class OrbFrameView(C.Structure):
+    _fields_ = [("kps", C.c_void_p), ("desc", C.c_void_p), ("n", C.c_int32),
+                ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float)]
+
+
+class BAProblem(C.Structure):
+    _fields_ = [("n_cams", C.c_int32), ("n_points", C.c_int32), ("n_obs", C.c_int32),
+                ("poses", C.c_void_p), ("fixed", C.c_void_p), ("points", C.c_void_p), ("obs", C.c_void_p),
+                ("cam_idx", C.c_void_p), ("pt_idx", C.c_void_p), ("inv_sigma2", C.c_void_p),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("huber_delta", C.c_double), ("n_rounds", C.c_int32), ("rounds", C.c_int32 * 4),
+                ("chi2_threshold", C.c_double), ("drop_robust_after", C.c_int32), ("stop", C.c_void_p)]
+
+
+class BAResult(C.Structure):
+    _fields_ = [("poses", C.c_void_p), ("points", C.c_void_p), ("outlier", C.c_void_p),
+                ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("iterations", C.c_int32),
+                ("lin_solves", C.c_int32)]
+
+
+# every symbol include/orbslam_amd.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "orb_last_error", "orb_device_count", "orb_create", "orb_destroy", "orb_get_levels", "orb_get_scale_factor",
+    "orb_get_tables", "orb_get_level_sizes", "orb_max_keypoints", "orb_extract", "orb_extract_batch",
+    "orb_extract_batch_device", "orb_download_level", "orb_download_candidates", "orb_synchronize", "orb_stream",
+    "orb_descriptor_distance", "orb_compute_three_maxima", "orb_matcher_create", "orb_matcher_destroy",
+    "orb_matcher_stream", "orb_matcher_synchronize", "orb_hamming_knn2", "orb_match_init",
+    "orb_match_batch_device", "ba_create", "ba_destroy", "ba_solve", "ba_solve_batch", "ba_pose_optimization",
+]
+
+_lib = None
+
+
+def build(verbose=False):
+    """compile csrc/*.hip for gfx950 into csrc/liborbslam_amd.so (hipcc cross-compiles without a GPU)"""
+    cmd = ["make", "-C", CSRC, "-j8"] + ([] if verbose else ["-s"])
+    subprocess.check_call(cmd)
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "orbslam_in_practice_amd: %s is missing -- build it with `make -C %s` (or "
+            "__graft_entry__.build()).  This package has no CPU fallback." % (LIB_PATH, CSRC))
+    L = C.CDLL(LIB_PATH)
+    vp, i32, f32, i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
+    L.orb_last_error.restype = C.c_char_p
+    L.orb_device_count.restype = C.c_int
+    L.orb_create.argtypes = [C.POINTER(OrbConfig), i32, i32, i32, i32, C.POINTER(vp)]
+    L.orb_destroy.argtypes = [vp]
+    L.orb_destroy.restype = None
+    L.orb_get_levels.argtypes = [vp]
+    L.orb_get_scale_factor.argtypes = [vp]
+    L.orb_get_scale_factor.restype = f32
+    L.orb_get_tables.argtypes = [vp] * 7
+    L.orb_get_level_sizes.argtypes = [vp, i32, i32, vp, vp]
+    L.orb_max_keypoints.argtypes = [vp]
+    L.orb_extract.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, vp]
+    L.orb_extract_batch.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp]
+    L.orb_extract_batch_device.argtypes = [vp, vp, i32, i32, i32, i32, i64, vp, vp, i32, vp, vp]
+    L.orb_download_level.argtypes = [vp, i32, i32, i32, vp]
+    L.orb_download_candidates.argtypes = [vp, i32, i32, vp, i32, vp]
+    L.orb_synchronize.argtypes = [vp]
+    L.orb_stream.argtypes = [vp]
+    L.orb_stream.restype = vp
+    L.orb_descriptor_distance.argtypes = [vp, vp]
+    L.orb_compute_three_maxima.argtypes = [vp, i32, vp, vp, vp]
+    L.orb_compute_three_maxima.restype = None
+    L.orb_matcher_create.argtypes = [i32, i32, i32, C.POINTER(vp)]
+    L.orb_matcher_destroy.argtypes = [vp]
+    L.orb_matcher_destroy.restype = None
+    L.orb_matcher_stream.argtypes = [vp]
+    L.orb_matcher_stream.restype = vp
+    L.orb_matcher_synchronize.argtypes = [vp]
+    L.orb_hamming_knn2.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp]
+    L.orb_match_init.argtypes = [vp, C.POINTER(OrbFrameView), C.POINTER(OrbFrameView), vp, vp, i32, f32, i32, vp]
+    L.orb_match_batch_device.argtypes = [vp, vp, vp, vp, i32, vp, vp, i32, f32, f32, f32, f32, i32, f32, i32, vp,
+                                         vp, vp]
+    if not hasattr(L, 'ba_create'):  # TEMP until ba_api.hip lands
+        _lib = L
+        return L
+    L.ba_create.argtypes = [i32, i32, i32, i32, i32, C.POINTER(vp)]
+    L.ba_destroy.argtypes = [vp]
+    L.ba_destroy.restype = None
+    L.ba_solve.argtypes = [vp, C.POINTER(BAProblem), C.POINTER(BAResult)]
+    L.ba_solve_batch.argtypes = [vp, C.POINTER(BAProblem), C.POINTER(BAResult), i32]
+    L.ba_pose_optimization.argtypes = [vp, vp, vp, vp, vp, i32, C.c_double, C.c_double, C.c_double, C.c_double,
+                                       vp, vp]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().orb_last_error()
+        raise OrbError(rc, msg.decode() if msg else "")
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)

@@ -1,0 +1,97 @@
+/* orb_common.h -- shared host/device structures of the gfx950 ORB front-end. */
+#ifndef ORB_COMMON_H
+#define ORB_COMMON_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/orbslam_amd.h"
+
+#define ORB_MAX_LEVELS 12
+#define ORB_EDGE_THRESHOLD 19
+#define ORB_MIN_BORDER 16      /* EDGE_THRESHOLD - 3, reference src/ORBextractor.cpp:729 */
+#define ORB_CELL_MAX 66        /* FAST cell ROI is at most (59+6) px on a side            */
+#define ORB_QT_MAX_NODES 1024  /* quadtree list capacity per (frame, level)               */
+#define ORB_QT_THREADS 512
+
+/* packed FAST candidate: window-relative x (12 bit) | y (12 bit) << 12 | score << 24 */
+#define KEY_X(k) ((int)((k) & 0xFFFu))
+#define KEY_Y(k) ((int)(((k) >> 12) & 0xFFFu))
+#define KEY_R(k) ((int)((k) >> 24))
+#define KEY_PACK(x, y, r) (((uint32_t)(x)) | ((uint32_t)(y) << 12) | ((uint32_t)(r) << 24))
+
+struct LevelGeom {
+    int w, h, pitch;          /* level size; bytes per row in the pyramid buffers                  */
+    int64_t plane_off;        /* byte offset of this level inside one frame's pyramid block        */
+    int maxBX, maxBY;         /* maxBorderX/Y (src/ORBextractor.cpp:731-732); minBorder = 16       */
+    int nCols, nRows, wCell, hCell; /* FAST cell grid (:740-743); nCols==0 -> level skipped         */
+    int cell_base;            /* first cell id of this level                                       */
+    int n_cells;              /* cells actually scanned on this level (row-major)                  */
+    int quota;                /* mnFeaturesPerLevel[level]                                         */
+    int out_cap;              /* quadtree output capacity                                          */
+    int out_base;             /* first output slot of this level in the per-frame level-kp array   */
+    int key_cap;              /* capacity of the per-level candidate arrays (NMS bound)            */
+    int64_t key_off;          /* offset (in keys) of this level inside one frame's key block       */
+    int nIni;                 /* quadtree root nodes (:493)                                        */
+    float hX;                 /* root node width (:495)                                            */
+    float scale;              /* mvScaleFactor[level]                                              */
+    float patch_size;         /* (int)(31*scale) as float (:793)                                   */
+    /* resize tables (level l from level l-1): offsets into the coefficient table buffer */
+    int xofs_off, yofs_off;   /* int index tables                                                  */
+};
+
+struct OrbGeom {
+    int nlevels, w, h;
+    int ini_th, min_th;
+    int total_cells;
+    int total_out_cap;        /* sum of out_cap                                                     */
+    int64_t pyr_frame_bytes;  /* bytes of one frame's pyramid block (all levels)                   */
+    int64_t key_frame_count;  /* keys of one frame's candidate block (all levels)                  */
+    int64_t slab_frame_count; /* keys of one frame's cell-slab block                               */
+    LevelGeom lv[ORB_MAX_LEVELS];
+};
+
+/* one FAST cell (reference src/ORBextractor.cpp:745-786) */
+struct CellDesc {
+    short level;
+    short rw, rh;     /* ROI size (incl. the 3-px rim FAST ignores)       */
+    short iniX, iniY; /* ROI origin in level coordinates                   */
+    short offX, offY; /* j*wCell, i*hCell: added to ROI-relative kp coords */
+    short pad;
+    int slab_off;     /* first slot of this cell in the frame's slab block */
+    int slab_cap;
+};
+
+struct OrbBuffers {
+    uint8_t *pyr;        /* [frame][pyr_frame_bytes]           un-blurred levels            */
+    uint8_t *blur;       /* same layout, blurred levels                                       */
+    uint32_t *slab;      /* [frame][slab_frame_count]          per-cell FAST output (packed) */
+    int32_t *cell_cnt;   /* [frame][total_cells]                                              */
+    uint32_t *keysA;     /* [frame][key_frame_count]           quadtree key buffers          */
+    uint32_t *keysB;
+    int32_t *cand_cnt;   /* [frame][nlevels]  candidates per level                            */
+    uint32_t *lvl_kp;    /* [frame][total_out_cap]  packed keys kept by the quadtree          */
+    int32_t *lvl_cnt;    /* [frame][nlevels]                                                  */
+    const CellDesc *cells;
+    const int32_t *tab_i;   /* xofs / yofs tables      */
+    const int16_t *tab_c;   /* ialpha / ibeta tables (2 per entry, same indexing *2) */
+};
+
+__host__ __device__ inline const uint8_t *level_ptr(const uint8_t *base, const OrbGeom &g, int frame, int level) {
+    return base + (int64_t)frame * g.pyr_frame_bytes + g.lv[level].plane_off;
+}
+__host__ __device__ inline uint8_t *level_ptr(uint8_t *base, const OrbGeom &g, int frame, int level) {
+    return base + (int64_t)frame * g.pyr_frame_bytes + g.lv[level].plane_off;
+}
+
+/* launchers (one per kernel family); all enqueue on `st` and return hipGetLastError() */
+hipError_t launch_pyramid(const OrbGeom &g, const OrbBuffers &b, const uint8_t *d_imgs, int stride,
+                          int64_t frame_stride, int n_frames, hipStream_t st);
+hipError_t launch_blur(const OrbGeom &g, const OrbBuffers &b, int n_frames, hipStream_t st);
+hipError_t launch_fast(const OrbGeom &g, const OrbBuffers &b, int n_frames, hipStream_t st);
+hipError_t launch_quadtree(const OrbGeom &g, const OrbBuffers &b, int n_frames, hipStream_t st);
+hipError_t orb_upload_constants();
+hipError_t launch_describe(const OrbGeom &g, const OrbBuffers &b, int n_frames, OrbKeyPoint *d_kps,
+                           uint8_t *d_desc, int cap, int32_t *d_counts, hipStream_t st);
+
+#endif

@@ -1,0 +1,179 @@
+/*
+ * orb_describe.hip -- intensity-centroid orientation, steered BRIEF-256 and output assembly: ONE
+ * wavefront per keypoint.
+ *
+ * Replaces computeOrientation/IC_Angle (reference src/ORBextractor.cpp:27-54, :422-429),
+ * computeOrbDescriptor (:58-97), the post-distribute fix-ups (:795-805) and the epilogue of
+ * operator() (:1019-1064: level-order concatenation, pt *= mvScaleFactor[level]).
+ *
+ *   - orientation: lanes 0..30 own the 31 columns u=-15..15 of the circular patch and walk its rows
+ *     (31 contiguous bytes per row: one coalesced segment), integer moments are reduced across the
+ *     wavefront with shuffles, cv::fastAtan2's f32 polynomial gives the angle;
+ *   - descriptor: lane L evaluates bits L, L+64, L+128, L+192 (two rotated u8 gathers each from the
+ *     BLURRED level); a wavefront ballot of each group IS 8 consecutive descriptor bytes;
+ *   - the rotation uses a deterministic double-precision sin/cos (same definition as the oracle's
+ *     ORC_TRIG_DET) and f32 mul/add without FMA contraction, then round-half-even (cvRound).
+ */
+#include "orb_common.h"
+
+__constant__ int8_t c_pattern[1024]; /* 256 x (x0,y0,x1,y1), reference src/ORBextractor.cpp:100-358 */
+static const int8_t h_pattern[1024] = {
+#include "orb_pattern_data.inc"
+};
+/* circular patch half-widths, derived by the reference ctor (:404-419) */
+__constant__ int8_t c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+    const float eps = (float)2.2204460492503131e-16;
+    float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + eps);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + eps);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+/* deterministic sin/cos: Cody-Waite reduction + fdlibm kernels in plain IEEE double (no FMA) */
+__device__ __forceinline__ void sincos_det(float angle, float *c_out, float *s_out) {
+    const double two_over_pi = 6.36619772367581382433e-01;
+    const double pio2_hi = 1.57079632673412561417e+00;
+    const double pio2_lo = 6.07710050650619224932e-11;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double x = (double)angle;
+    double kd = rint(x * two_over_pi);
+    int k = (int)kd;
+    double r = (x - kd * pio2_hi) - kd * pio2_lo;
+    double z = r * r;
+    double ps = S1 + z * (S2 + z * (S3 + z * (S4 + z * (S5 + z * S6))));
+    double sn = r + (r * z) * ps;
+    double pc = C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6))));
+    double cs = (1.0 - 0.5 * z) + (z * z) * pc;
+    double sv, cv;
+    switch (k & 3) {
+    case 0: sv = sn; cv = cs; break;
+    case 1: sv = cs; cv = -sn; break;
+    case 2: sv = -sn; cv = -cs; break;
+    default: sv = -cs; cv = sn; break;
+    }
+    *c_out = (float)cv;
+    *s_out = (float)sv;
+}
+
+__global__ __launch_bounds__(256) void k_describe(OrbGeom g, const uint8_t *pyr, const uint8_t *blur,
+                                                   const uint32_t *lvl_kp, const int32_t *lvl_cnt, OrbKeyPoint *kps,
+                                                   uint8_t *desc, int cap, int32_t *counts) {
+    const int frame = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6); /* slot in the frame's level-kp array */
+    const int32_t *lc = lvl_cnt + (int64_t)frame * g.nlevels;
+    int level = 0, before = 0;
+    while (level + 1 < g.nlevels && slot >= g.lv[level + 1].out_base) {
+        before += lc[level];
+        level++;
+    }
+    if (slot == 0 && lane == 0) {
+        int tot = 0;
+        for (int l = 0; l < g.nlevels; l++) tot += lc[l];
+        counts[frame] = tot < cap ? tot : cap;
+    }
+    if (slot >= g.total_out_cap) return;
+    const LevelGeom &L = g.lv[level];
+    const int idx = slot - L.out_base;
+    if (idx >= lc[level]) return;
+    const int oi = before + idx; /* position in the concatenated output (:1035-1063) */
+    if (oi >= cap) return;
+    const uint32_t key = lvl_kp[(int64_t)frame * g.total_out_cap + slot];
+    const int px = KEY_X(key) + ORB_MIN_BORDER, py = KEY_Y(key) + ORB_MIN_BORDER; /* :799-800 */
+
+    /* ---- IC_Angle on the un-blurred level ---- */
+    const uint8_t *img = level_ptr(pyr, g, frame, level);
+    const uint8_t *center = img + (int64_t)py * L.pitch + px;
+    int m10 = 0, m01 = 0;
+    {
+        const int u = lane - 15;
+        if (lane < 31) {
+            m10 = u * (int)center[u];
+#pragma unroll
+            for (int v = 1; v <= 15; v++) {
+                if (u >= -c_umax[v] && u <= c_umax[v]) {
+                    int vp = center[u + v * L.pitch], vm = center[u - v * L.pitch];
+                    m01 += v * (vp - vm);
+                    m10 += u * (vp + vm);
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            m10 += __shfl_xor(m10, o);
+            m01 += __shfl_xor(m01, o);
+        }
+    }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+    /* ---- steered BRIEF on the blurred level ---- */
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    float a, b;
+    sincos_det(angle * factorPI, &a, &b);
+    const uint8_t *bc = level_ptr(blur, g, frame, level) + (int64_t)py * L.pitch + px;
+    uint64_t words[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int bit = j * 64 + lane;
+        const int8_t *p = c_pattern + bit * 4;
+        const float x0 = (float)p[0], y0 = (float)p[1], x1 = (float)p[2], y1 = (float)p[3];
+        const int r0 = (int)rintf(x0 * b + y0 * a), q0 = (int)rintf(x0 * a - y0 * b);
+        const int r1 = (int)rintf(x1 * b + y1 * a), q1 = (int)rintf(x1 * a - y1 * b);
+        const int t0 = bc[r0 * L.pitch + q0], t1 = bc[r1 * L.pitch + q1];
+        words[j] = __ballot(t0 < t1);
+    }
+    if (lane < 4) {
+        uint64_t w = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
+        *(uint64_t *)(desc + ((int64_t)frame * cap + oi) * 32 + lane * 8) = w;
+    }
+    if (lane == 0) {
+        OrbKeyPoint kp;
+        float fx = (float)px, fy = (float)py;
+        if (level != 0) { /* :1055-1061 */
+            fx *= L.scale;
+            fy *= L.scale;
+        }
+        kp.x = fx;
+        kp.y = fy;
+        kp.size = L.patch_size;
+        kp.angle = angle;
+        kp.response = (float)KEY_R(key);
+        kp.octave = level;
+        kp.class_id = -1;
+        kps[(int64_t)frame * cap + oi] = kp;
+    }
+}
+
+/* one-time (per device) upload of the sampling pattern; called from orb_create, never from a launch path */
+hipError_t orb_upload_constants() {
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), h_pattern, sizeof(h_pattern));
+}
+
+hipError_t launch_describe(const OrbGeom &g, const OrbBuffers &b, int n_frames, OrbKeyPoint *d_kps, uint8_t *d_desc,
+                           int cap, int32_t *d_counts, hipStream_t st) {
+    dim3 grid((g.total_out_cap + 3) / 4, n_frames);
+    hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, st, g, (const uint8_t *)b.pyr, (const uint8_t *)b.blur,
+                       (const uint32_t *)b.lvl_kp, (const int32_t *)b.lvl_cnt, d_kps, d_desc, cap, d_counts);
+    return hipGetLastError();
+}

@@ -1,0 +1,156 @@
+/*
+ * orb_fast.hip -- per-cell FAST-9/16 corner scoring, 3x3 non-max suppression and the two-threshold
+ * fallback of ORBextractor::ComputeKeyPointsOctTree (reference src/ORBextractor.cpp:745-786), all
+ * cells of all levels of all frames in ONE launch: one 256-thread workgroup per (cell, frame).
+ *
+ *   - the cell ROI (<= 65x65 u8, incl. the 3-px rim cv::FAST ignores) is staged in LDS with
+ *     row-coalesced loads;
+ *   - every interior pixel gets its cornerScore (largest threshold at which it is still a 9/16
+ *     corner) from 16 LDS ring reads; "corner at threshold t"  <=>  score >= t, so ONE scoring pass
+ *     serves both iniThFAST and minThFAST;
+ *   - NMS keeps a pixel iff its score is strictly greater than its 8 neighbours INSIDE the cell's
+ *     detection zone (scores outside are 0, exactly like cv::FAST on the cell ROI);
+ *   - if no pixel survives at iniThFAST the cell falls back to minThFAST (per-cell decision);
+ *   - survivors are emitted in the reference's order (row-major inside the cell) into the cell's slab
+ *     slot with a wavefront ballot/popcount compaction -- no atomics, deterministic order.
+ *
+ * NMS on scores >= minTh followed by filtering at iniTh equals cv::FAST(iniTh, nms=true): a neighbour
+ * whose score is below iniTh can never beat a pixel whose score is >= iniTh.
+ */
+#include "orb_common.h"
+
+#define FT_LD 68 /* LDS row pitch */
+
+__device__ __forceinline__ int fast_score16(const uint8_t *c, int v) {
+    /* ring in OpenCV's order: (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)
+       (-3,0)(-3,1)(-2,2)(-1,3) */
+    int d[16];
+    d[0] = v - c[3 * FT_LD + 0];
+    d[1] = v - c[3 * FT_LD + 1];
+    d[2] = v - c[2 * FT_LD + 2];
+    d[3] = v - c[1 * FT_LD + 3];
+    d[4] = v - c[3];
+    d[5] = v - c[-1 * FT_LD + 3];
+    d[6] = v - c[-2 * FT_LD + 2];
+    d[7] = v - c[-3 * FT_LD + 1];
+    d[8] = v - c[-3 * FT_LD + 0];
+    d[9] = v - c[-3 * FT_LD - 1];
+    d[10] = v - c[-2 * FT_LD - 2];
+    d[11] = v - c[-1 * FT_LD - 3];
+    d[12] = v - c[-3];
+    d[13] = v - c[1 * FT_LD - 3];
+    d[14] = v - c[2 * FT_LD - 2];
+    d[15] = v - c[3 * FT_LD - 1];
+    /* max over the 16 nine-arcs of min(d) (dark ring) and of min(-d) (bright ring): log-step windows */
+    int lo2[16], hi2[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        lo2[k] = min(d[k], d[(k + 1) & 15]);
+        hi2[k] = max(d[k], d[(k + 1) & 15]);
+    }
+    int lo4[16], hi4[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        lo4[k] = min(lo2[k], lo2[(k + 2) & 15]);
+        hi4[k] = max(hi2[k], hi2[(k + 2) & 15]);
+    }
+    int a = -1000, b = 1000;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
+        int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
+        a = max(a, lo9);
+        b = min(b, hi9);
+    }
+    return max(a, -b) - 1;
+}
+
+__global__ __launch_bounds__(256) void k_fast_cells(OrbGeom g, const uint8_t *pyr, const CellDesc *cells,
+                                                     uint32_t *slab, int32_t *cell_cnt) {
+    __shared__ uint8_t s_px[ORB_CELL_MAX][FT_LD];
+    __shared__ uint8_t s_sc[ORB_CELL_MAX][FT_LD];
+    __shared__ int s_wave[4];
+    __shared__ int s_any;
+    const int cell = blockIdx.x, frame = blockIdx.y;
+    const CellDesc cd = cells[cell];
+    const LevelGeom &L = g.lv[cd.level];
+    const int rw = cd.rw, rh = cd.rh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint8_t *src = level_ptr(pyr, g, frame, cd.level) + (int64_t)cd.iniY * L.pitch + cd.iniX;
+    /* stage ROI: one wave per row, lanes along x (row-coalesced) ; zero the score tile */
+    for (int r = wave; r < rh; r += 4) {
+        const uint8_t *row = src + (int64_t)r * L.pitch;
+        for (int c = lane; c < rw; c += 64) s_px[r][c] = row[c];
+    }
+    for (int i = tid; i < ORB_CELL_MAX * FT_LD; i += 256) (&s_sc[0][0])[i] = 0;
+    if (tid == 0) s_any = 0;
+    __syncthreads();
+    const int iw = rw - 6, ih = rh - 6; /* detection zone */
+    const int n_in = (iw > 0 && ih > 0) ? iw * ih : 0;
+    /* scores (0 when not a corner at minThFAST) */
+    for (int i = tid; i < n_in; i += 256) {
+        int y = i / iw, x = i - y * iw;
+        const uint8_t *c = &s_px[y + 3][x + 3];
+        int s = fast_score16(c, (int)c[0]);
+        s_sc[y + 3][x + 3] = (uint8_t)(s >= g.min_th ? s : 0);
+    }
+    __syncthreads();
+    /* NMS: strictly greater than the 8 neighbours.  Each thread owns a contiguous run of the row-major
+       order so that the compaction below needs a single block scan. */
+    const int per = (n_in + 255) / 256;
+    const int beg = min(tid * per, n_in), end = min(beg + per, n_in);
+    int any_ini = 0;
+    uint32_t keep_lo = 0; /* per <= 14 (59*59/256) : bit k = element beg+k kept */
+    for (int i = beg; i < end; i++) {
+        int y = i / iw + 3, x = i - (y - 3) * iw + 3;
+        int s = s_sc[y][x];
+        bool k = s > 0 && s > s_sc[y - 1][x - 1] && s > s_sc[y - 1][x] && s > s_sc[y - 1][x + 1] &&
+                 s > s_sc[y][x - 1] && s > s_sc[y][x + 1] && s > s_sc[y + 1][x - 1] && s > s_sc[y + 1][x] &&
+                 s > s_sc[y + 1][x + 1];
+        if (k) {
+            keep_lo |= 1u << (i - beg);
+            any_ini |= (s >= g.ini_th);
+        }
+    }
+    if (any_ini) s_any = 1; /* benign race: all writers store 1 */
+    __syncthreads();
+    const int th = s_any ? g.ini_th : g.min_th;
+    int mine = 0;
+    uint32_t sel = 0;
+    for (int i = beg; i < end; i++) {
+        if (keep_lo & (1u << (i - beg))) {
+            int y = i / iw + 3, x = i - (y - 3) * iw + 3;
+            if (s_sc[y][x] >= th) {
+                sel |= 1u << (i - beg);
+                mine++;
+            }
+        }
+    }
+    /* block exclusive scan of `mine` in thread order: wave scan by shuffles + 4 wave totals */
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; w++) base += s_wave[w];
+    int pos = base + incl - mine;
+    uint32_t *out = slab + (int64_t)frame * g.slab_frame_count + cd.slab_off;
+    for (int i = beg; i < end; i++) {
+        if (sel & (1u << (i - beg))) {
+            int y = i / iw + 3, x = i - (y - 3) * iw + 3;
+            out[pos++] = KEY_PACK(x + cd.offX, y + cd.offY, s_sc[y][x]);
+        }
+    }
+    if (tid == 255) cell_cnt[(int64_t)frame * g.total_cells + cell] = base + incl;
+}
+
+hipError_t launch_fast(const OrbGeom &g, const OrbBuffers &b, int n_frames, hipStream_t st) {
+    if (g.total_cells == 0) return hipSuccess;
+    dim3 grid(g.total_cells, n_frames);
+    hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, st, g, (const uint8_t *)b.pyr, b.cells, b.slab, b.cell_cnt);
+    return hipGetLastError();
+}

@@ -1,0 +1,504 @@
+/*
+ * orb_match.hip -- ORBmatcher on gfx950: Hamming distances with v_xor / v_bcnt (popcount) and
+ * wavefront min-reductions.
+ *
+ *   k_hamming_knn2   brute-force 2-NN (north_star / SURVEY a12): one query descriptor per lane in
+ *                    8 VGPRs, the train set streamed through LDS in 1024-descriptor tiles and read
+ *                    back as wave-wide broadcasts (conflict free), ties -> lowest index.
+ *   k_match_init     ORBmatcher::SearchForInitialization (reference src/ORBmatcher.cpp:9-126) with
+ *                    Frame::GetFeaturesInArea (src/Frame.cpp:219-271): ONE wavefront per frame pair.
+ *                    The reference loop over i1 carries a dependency (a later i1 may only take an i2
+ *                    whose recorded match distance is larger, :49-50), so i1 is walked in order while
+ *                    the candidate scan of each i1 is spread over the 64 lanes and finished with a
+ *                    wave reduction on (distance, grid order) keys.
+ *
+ * Candidate set and order of GetFeaturesInArea without materialising the 64x48 grid: an F2 keypoint is
+ * a candidate iff it was assigned to the grid (round((p-min)*inv) inside the grid, src/Frame.cpp:
+ * 161-168 with the miMaxY typo corrected), passes the octave filter and lies strictly inside the
+ * square window; the cell range [floor((x-r)*inv), ceil((x+r)*inv)] can never exclude such a point.
+ * The reference visits candidates by (cell x, cell y, insertion order); only the FIRST minimum
+ * depends on that order, so each candidate carries the key (dist << 32 | cell << 16 | index).
+ */
+#include "orb_common.h"
+
+#include <cstring>
+#include <string>
+
+#define GRID_COLS 64
+#define GRID_ROWS 48
+#define HISTO_LENGTH 30
+#define TH_LOW 50
+
+__device__ __forceinline__ int hamming256(const uint32_t a[8], const uint4 b0, const uint4 b1) {
+    return __popc(a[0] ^ b0.x) + __popc(a[1] ^ b0.y) + __popc(a[2] ^ b0.z) + __popc(a[3] ^ b0.w) +
+           __popc(a[4] ^ b1.x) + __popc(a[5] ^ b1.y) + __popc(a[6] ^ b1.z) + __popc(a[7] ^ b1.w);
+}
+
+#define KNN_TILE 1024
+__global__ __launch_bounds__(256) void k_hamming_knn2(const uint8_t *d1, int n1, const uint8_t *d2, int n2,
+                                                       int32_t *idx, uint16_t *best, uint16_t *second) {
+    __shared__ uint4 s_d2[KNN_TILE * 2];
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (q < n1) {
+        const uint4 *p = (const uint4 *)(d1 + (size_t)q * 32);
+        uint4 v0 = p[0], v1 = p[1];
+        a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w;
+        a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
+    }
+    int b1 = 0x7FFFFFFF, b2 = 0x7FFFFFFF, bi = -1;
+    for (int t0 = 0; t0 < n2; t0 += KNN_TILE) {
+        const int nt = min(KNN_TILE, n2 - t0);
+        __syncthreads();
+        const uint4 *src = (const uint4 *)(d2 + (size_t)t0 * 32);
+        for (int i = threadIdx.x; i < nt * 2; i += 256) s_d2[i] = src[i]; /* 16 B per lane, coalesced */
+        __syncthreads();
+        for (int j = 0; j < nt; j++) {
+            const int d = hamming256(a, s_d2[2 * j], s_d2[2 * j + 1]);
+            if (d < b1) {
+                b2 = b1;
+                b1 = d;
+                bi = t0 + j;
+            } else if (d < b2)
+                b2 = d;
+        }
+    }
+    if (q < n1) {
+        idx[q] = bi;
+        best[q] = (uint16_t)(b1 == 0x7FFFFFFF ? 0xFFFF : b1);
+        second[q] = (uint16_t)(b2 == 0x7FFFFFFF ? 0xFFFF : b2);
+    }
+}
+
+struct MatchArgs {
+    const OrbKeyPoint *kps;  /* frame slabs: kps[frame*cap + i]           */
+    const uint8_t *desc;     /* desc[(frame*cap + i)*32]                  */
+    const int32_t *counts;   /* counts[frame]                             */
+    int cap;
+    const int32_t *pair_a, *pair_b; /* NULL: pair p = (2p, 2p+1)           */
+    const float *prev_xy;    /* NULL: prev matched = F1 keypoint positions; else [pair][cap][2] */
+    float *prev_out;         /* optional updated prev matched              */
+    float min_x, max_x, min_y, max_y;
+    int window;              /* < 0: brute force variant                   */
+    float nnratio;
+    int check_ori;
+    int32_t *matches12;      /* [pair][cap]                                */
+    int32_t *nmatches;       /* [pair]                                     */
+    uint8_t *bin_scratch;    /* [pair][cap] rotation bin of each i1        */
+};
+
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint64_t t = __shfl_xor(v, o);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        int t = __shfl_xor(v, o);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+
+/* one wavefront per frame pair; dynamic LDS: per F2 keypoint {float x,y; u32 ord; i32 m21; u16 mdist} */
+__global__ __launch_bounds__(64) void k_match_init(MatchArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int pair = blockIdx.x, lane = threadIdx.x;
+    const int fa = A.pair_a ? A.pair_a[pair] : 2 * pair, fb = A.pair_b ? A.pair_b[pair] : 2 * pair + 1;
+    const int n1 = A.counts[fa], n2 = A.counts[fb];
+    const OrbKeyPoint *k1 = A.kps + (size_t)fa * A.cap, *k2 = A.kps + (size_t)fb * A.cap;
+    const uint8_t *D1 = A.desc + (size_t)fa * A.cap * 32, *D2 = A.desc + (size_t)fb * A.cap * 32;
+    float *s_x = (float *)smem;
+    float *s_y = s_x + A.cap;
+    uint32_t *s_ord = (uint32_t *)(s_y + A.cap); /* 0xFFFFFFFF = not a candidate for anybody */
+    int32_t *s_m21 = (int32_t *)(s_ord + A.cap);
+    uint16_t *s_md = (uint16_t *)(s_m21 + A.cap); /* 0xFFFF = INT_MAX */
+    __shared__ int s_hist[HISTO_LENGTH];
+    int32_t *m12 = A.matches12 + (size_t)pair * A.cap;
+    uint8_t *bins = A.bin_scratch + (size_t)pair * A.cap;
+    const bool brute = A.window < 0;
+    const float invW = (float)GRID_COLS / (A.max_x - A.min_x); /* src/Frame.cpp:59-60 */
+    const float invH = (float)GRID_ROWS / (A.max_y - A.min_y);
+    for (int j = lane; j < n2; j += 64) {
+        const OrbKeyPoint kp = k2[j];
+        s_x[j] = kp.x;
+        s_y[j] = kp.y;
+        uint32_t ord = 0xFFFFFFFFu;
+        if (brute) {
+            ord = (uint32_t)j;
+        } else if (kp.octave == 0) { /* GetFeaturesInArea(.., level1, level1) with level1 == 0 */
+            const int ix = (int)round(((double)kp.x - (double)A.min_x) * (double)invW);
+            const int iy = (int)round(((double)kp.y - (double)A.min_y) * (double)invH);
+            if (ix >= 0 && ix < GRID_COLS && iy >= 0 && iy < GRID_ROWS)
+                ord = ((uint32_t)(ix * GRID_ROWS + iy) << 16) | (uint32_t)j;
+        }
+        s_ord[j] = ord;
+        s_m21[j] = -1;
+        s_md[j] = 0xFFFF;
+    }
+    for (int i = lane; i < n1; i += 64) {
+        m12[i] = -1;
+        bins[i] = 0xFF;
+    }
+    if (lane < HISTO_LENGTH) s_hist[lane] = 0;
+    __syncthreads();
+    const float r = (float)A.window;
+    const float factor = HISTO_LENGTH / 360.0f;
+    for (int i1 = 0; i1 < n1; i1++) {
+        const OrbKeyPoint kp1 = k1[i1];
+        if (!brute && kp1.octave > 0) continue;
+        float px = kp1.x, py = kp1.y;
+        if (A.prev_xy) {
+            px = A.prev_xy[((size_t)pair * A.cap + i1) * 2];
+            py = A.prev_xy[((size_t)pair * A.cap + i1) * 2 + 1];
+        }
+        uint32_t a[8];
+        {
+            const uint4 *p = (const uint4 *)(D1 + (size_t)i1 * 32);
+            uint4 v0 = p[0], v1 = p[1];
+            a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w;
+            a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
+        }
+        uint64_t bestKey = ~0ull; /* dist << 32 | ord */
+        int second = 0x7FFFFFFF;
+        for (int j = lane; j < n2; j += 64) {
+            const uint32_t ord = s_ord[j];
+            bool cand = ord != 0xFFFFFFFFu;
+            if (cand && !brute) {
+                const float dx = s_x[j] - px, dy = s_y[j] - py;
+                cand = fabsf(dx) < r && fabsf(dy) < r;
+            }
+            if (cand) {
+                const uint4 *p = (const uint4 *)(D2 + (size_t)j * 32);
+                const int d = hamming256(a, p[0], p[1]);
+                const int md = s_md[j] == 0xFFFF ? 0x7FFFFFFF : (int)s_md[j];
+                if (!(md <= d)) { /* :49-50 */
+                    const uint64_t key = ((uint64_t)(uint32_t)d << 32) | ord;
+                    if (key < bestKey) {
+                        if (bestKey != ~0ull) second = min(second, (int)(bestKey >> 32));
+                        bestKey = key;
+                    } else
+                        second = min(second, d);
+                }
+            }
+        }
+        const uint64_t gKey = wave_min_u64(bestKey);
+        const int alt = (bestKey == gKey) ? second : (bestKey == ~0ull ? 0x7FFFFFFF : (int)(bestKey >> 32));
+        const int bestDist2 = wave_min_i32(alt);
+        if (gKey != ~0ull) {
+            const int bestDist = (int)(gKey >> 32);
+            const int bestIdx2 = (int)(gKey & 0xFFFFu);
+            if (bestDist <= TH_LOW && (float)bestDist < (float)bestDist2 * A.nnratio) {
+                if (lane == 0) {
+                    const int old = s_m21[bestIdx2];
+                    if (old >= 0) m12[old] = -1;
+                    m12[i1] = bestIdx2;
+                    s_m21[bestIdx2] = i1;
+                    s_md[bestIdx2] = (uint16_t)bestDist;
+                    if (A.check_ori) {
+                        float rot = kp1.angle - k2[bestIdx2].angle;
+                        if (rot < 0.0f) rot += 360.0f;
+                        int bin = (int)roundf(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        bins[i1] = (uint8_t)bin;
+                        s_hist[bin]++;
+                    }
+                }
+            }
+        }
+        __syncthreads(); /* lane 0's LDS updates before the next scan (single-wave workgroup) */
+    }
+    /* nmatches == number of i1 with m12 >= 0 (every accept adds one and every steal removes one) */
+    __threadfence_block();
+    __syncthreads();
+    if (A.check_ori) { /* :95-118 with ComputeThreeMaxima :147-188 */
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        int max1 = 0, max2 = 0, max3 = 0;
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            const int s = s_hist[i];
+            if (s > max1) {
+                max3 = max2; max2 = max1; max1 = s;
+                ind3 = ind2; ind2 = ind1; ind1 = i;
+            } else if (s > max2) {
+                max3 = max2; max2 = s;
+                ind3 = ind2; ind2 = i;
+            } else if (s > max3) {
+                max3 = s;
+                ind3 = i;
+            }
+        }
+        if (max2 < 0.1f * (float)max1) {
+            ind2 = -1;
+            ind3 = -1;
+        } else if (max3 < 0.1f * (float)max1) {
+            ind3 = -1;
+        }
+        for (int i = lane; i < n1; i += 64) {
+            const int b = bins[i];
+            if (b != 0xFF && b != ind1 && b != ind2 && b != ind3 && m12[i] >= 0) m12[i] = -1;
+        }
+        __syncthreads();
+    }
+    int cnt = 0;
+    for (int i = lane; i < n1; i += 64) {
+        const int m = m12[i];
+        if (m >= 0) {
+            cnt++;
+            if (A.prev_out) {
+                A.prev_out[((size_t)pair * A.cap + i) * 2] = s_x[m];
+                A.prev_out[((size_t)pair * A.cap + i) * 2 + 1] = s_y[m];
+            }
+        } else if (A.prev_out && A.prev_xy) {
+            A.prev_out[((size_t)pair * A.cap + i) * 2] = A.prev_xy[((size_t)pair * A.cap + i) * 2];
+            A.prev_out[((size_t)pair * A.cap + i) * 2 + 1] = A.prev_xy[((size_t)pair * A.cap + i) * 2 + 1];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (lane == 0) A.nmatches[pair] = cnt;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+static thread_local std::string m_err;
+#define MCHK(expr)                                                                         \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            m_err = std::string(#expr) + ": " + hipGetErrorString(_e);                     \
+            return ORB_E_HIP;                                                              \
+        }                                                                                  \
+    } while (0)
+
+struct OrbMatcher {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int max_kp = 0, max_pairs = 0;
+    /* host-API staging: two frames */
+    OrbKeyPoint *d_kps = nullptr; /* [2][max_kp] */
+    uint8_t *d_desc = nullptr;    /* [2][max_kp][32] */
+    int32_t *d_counts = nullptr;  /* [2] */
+    float *d_prev = nullptr, *d_prev_out = nullptr; /* [max_kp][2] */
+    int32_t *d_m12 = nullptr;     /* [max_pairs][max_kp] */
+    int32_t *d_nm = nullptr;      /* [max_pairs] */
+    uint8_t *d_bins = nullptr;    /* [max_pairs][max_kp] */
+    int32_t *d_idx = nullptr;
+    uint16_t *d_best = nullptr, *d_second = nullptr;
+};
+
+extern "C" int orb_matcher_create(int max_keypoints, int max_pairs, int device_id, OrbMatcher **out) {
+    if (!out || max_keypoints <= 0 || max_pairs <= 0 || max_keypoints > 65535) return ORB_E_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return ORB_E_NO_DEVICE;
+    MCHK(hipSetDevice(device_id));
+    OrbMatcher *m = new OrbMatcher();
+    m->device = device_id;
+    m->max_kp = max_keypoints;
+    m->max_pairs = max_pairs;
+    const size_t K = (size_t)max_keypoints;
+    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void **)&m->d_kps, 2 * K * sizeof(OrbKeyPoint)) != hipSuccess ||
+        hipMalloc((void **)&m->d_desc, 2 * K * 32) != hipSuccess || hipMalloc((void **)&m->d_counts, 16) != hipSuccess ||
+        hipMalloc((void **)&m->d_prev, K * 8) != hipSuccess || hipMalloc((void **)&m->d_prev_out, K * 8) != hipSuccess ||
+        hipMalloc((void **)&m->d_m12, (size_t)max_pairs * K * 4) != hipSuccess ||
+        hipMalloc((void **)&m->d_nm, (size_t)max_pairs * 4) != hipSuccess ||
+        hipMalloc((void **)&m->d_bins, (size_t)max_pairs * K) != hipSuccess ||
+        hipMalloc((void **)&m->d_idx, K * 4) != hipSuccess || hipMalloc((void **)&m->d_best, K * 2) != hipSuccess ||
+        hipMalloc((void **)&m->d_second, K * 2) != hipSuccess) {
+        orb_matcher_destroy(m);
+        return ORB_E_HIP;
+    }
+    *out = m;
+    return ORB_OK;
+}
+
+extern "C" void orb_matcher_destroy(OrbMatcher *m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    (void)hipFree(m->d_kps);
+    (void)hipFree(m->d_desc);
+    (void)hipFree(m->d_counts);
+    (void)hipFree(m->d_prev);
+    (void)hipFree(m->d_prev_out);
+    (void)hipFree(m->d_m12);
+    (void)hipFree(m->d_nm);
+    (void)hipFree(m->d_bins);
+    (void)hipFree(m->d_idx);
+    (void)hipFree(m->d_best);
+    (void)hipFree(m->d_second);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+extern "C" void *orb_matcher_stream(OrbMatcher *m) { return m ? (void *)m->stream : nullptr; }
+extern "C" int orb_matcher_synchronize(OrbMatcher *m) {
+    if (!m) return ORB_E_INVALID;
+    MCHK(hipSetDevice(m->device));
+    MCHK(hipStreamSynchronize(m->stream));
+    return ORB_OK;
+}
+
+/* ORBmatcher::DescriptorDistance, src/ORBmatcher.cpp:128-144 (host-side scalar; same SWAR popcount) */
+extern "C" int orb_descriptor_distance(const uint8_t *a, const uint8_t *b) {
+    uint32_t pa[8], pb[8];
+    memcpy(pa, a, 32);
+    memcpy(pb, b, 32);
+    int dist = 0;
+    for (int i = 0; i < 8; i++) {
+        uint32_t v = pa[i] ^ pb[i];
+        v = v - ((v >> 1) & 0x55555555u);
+        v = (v & 0x33333333u) + ((v >> 2) & 0x33333333u);
+        dist += (int)((((v + (v >> 4)) & 0xF0F0F0Fu) * 0x1010101u) >> 24);
+    }
+    return dist;
+}
+
+/* ORBmatcher::ComputeThreeMaxima, src/ORBmatcher.cpp:147-188 */
+extern "C" void orb_compute_three_maxima(const int32_t *histo, int L, int32_t *i1, int32_t *i2, int32_t *i3) {
+    int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+    for (int i = 0; i < L; i++) {
+        const int s = histo[i];
+        if (s > max1) {
+            max3 = max2; max2 = max1; max1 = s;
+            ind3 = ind2; ind2 = ind1; ind1 = i;
+        } else if (s > max2) {
+            max3 = max2; max2 = s;
+            ind3 = ind2; ind2 = i;
+        } else if (s > max3) {
+            max3 = s;
+            ind3 = i;
+        }
+    }
+    if (max2 < 0.1f * (float)max1) {
+        ind2 = -1;
+        ind3 = -1;
+    } else if (max3 < 0.1f * (float)max1) {
+        ind3 = -1;
+    }
+    *i1 = ind1;
+    *i2 = ind2;
+    *i3 = ind3;
+}
+
+extern "C" int orb_hamming_knn2(OrbMatcher *m, const uint8_t *d1, int n1, const uint8_t *d2, int n2, int32_t *idx,
+                                uint16_t *best, uint16_t *second) {
+    if (!m || n1 < 0 || n2 < 0 || (n1 > 0 && (!d1 || !idx || !best || !second)) || (n2 > 0 && !d2)) return ORB_E_INVALID;
+    if (n1 > m->max_kp || n2 > m->max_kp) return ORB_E_CAPACITY;
+    if (n1 == 0) return ORB_OK;
+    MCHK(hipSetDevice(m->device));
+    MCHK(hipMemcpyAsync(m->d_desc, d1, (size_t)n1 * 32, hipMemcpyHostToDevice, m->stream));
+    if (n2 > 0)
+        MCHK(hipMemcpyAsync(m->d_desc + (size_t)m->max_kp * 32, d2, (size_t)n2 * 32, hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(k_hamming_knn2, dim3((n1 + 255) / 256), dim3(256), 0, m->stream, (const uint8_t *)m->d_desc, n1,
+                       (const uint8_t *)(m->d_desc + (size_t)m->max_kp * 32), n2, m->d_idx, m->d_best, m->d_second);
+    MCHK(hipGetLastError());
+    MCHK(hipMemcpyAsync(idx, m->d_idx, (size_t)n1 * 4, hipMemcpyDeviceToHost, m->stream));
+    MCHK(hipMemcpyAsync(best, m->d_best, (size_t)n1 * 2, hipMemcpyDeviceToHost, m->stream));
+    MCHK(hipMemcpyAsync(second, m->d_second, (size_t)n1 * 2, hipMemcpyDeviceToHost, m->stream));
+    MCHK(hipStreamSynchronize(m->stream));
+    return ORB_OK;
+}
+
+static size_t match_lds_bytes(int cap) { return (size_t)cap * (4 + 4 + 4 + 4 + 2) + 64; }
+
+static int launch_match(const MatchArgs &A, int n_pairs, hipStream_t st) {
+    const size_t lds = match_lds_bytes(A.cap);
+    if (lds > 160 * 1024 - 1024) {
+        m_err = "matcher: keypoint capacity too large for the LDS-resident frame state";
+        return ORB_E_CAPACITY;
+    }
+    static size_t attr_set = 0;
+    if (lds > attr_set) {
+        MCHK(hipFuncSetAttribute((const void *)k_match_init, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = lds;
+    }
+    hipLaunchKernelGGL(k_match_init, dim3(n_pairs), dim3(64), lds, st, A);
+    MCHK(hipGetLastError());
+    return ORB_OK;
+}
+
+extern "C" int orb_match_init(OrbMatcher *m, const OrbFrameView *f1, const OrbFrameView *f2, float *prev_matched_xy,
+                              int32_t *matches12, int window_size, float nnratio, int check_orientation,
+                              int32_t *n_matches) {
+    if (!m || !f1 || !f2 || !n_matches || f1->n < 0 || f2->n < 0 || (f1->n > 0 && (!matches12 || !f1->kps || !f1->desc)) ||
+        (f2->n > 0 && (!f2->kps || !f2->desc)) || (window_size >= 0 && f1->n > 0 && !prev_matched_xy))
+        return ORB_E_INVALID;
+    if (f1->n > m->max_kp || f2->n > m->max_kp) return ORB_E_CAPACITY;
+    *n_matches = 0;
+    if (f1->n == 0) return ORB_OK;
+    MCHK(hipSetDevice(m->device));
+    const size_t K = (size_t)m->max_kp;
+    int32_t counts[2] = {f1->n, f2->n};
+    MCHK(hipMemcpyAsync(m->d_counts, counts, 8, hipMemcpyHostToDevice, m->stream));
+    MCHK(hipMemcpyAsync(m->d_kps, f1->kps, (size_t)f1->n * sizeof(OrbKeyPoint), hipMemcpyHostToDevice, m->stream));
+    MCHK(hipMemcpyAsync(m->d_desc, f1->desc, (size_t)f1->n * 32, hipMemcpyHostToDevice, m->stream));
+    if (f2->n > 0) {
+        MCHK(hipMemcpyAsync(m->d_kps + K, f2->kps, (size_t)f2->n * sizeof(OrbKeyPoint), hipMemcpyHostToDevice, m->stream));
+        MCHK(hipMemcpyAsync(m->d_desc + K * 32, f2->desc, (size_t)f2->n * 32, hipMemcpyHostToDevice, m->stream));
+    }
+    if (prev_matched_xy)
+        MCHK(hipMemcpyAsync(m->d_prev, prev_matched_xy, (size_t)f1->n * 8, hipMemcpyHostToDevice, m->stream));
+    MatchArgs A{};
+    A.kps = m->d_kps;
+    A.desc = m->d_desc;
+    A.counts = m->d_counts;
+    A.cap = m->max_kp;
+    A.pair_a = nullptr;
+    A.pair_b = nullptr;
+    A.prev_xy = prev_matched_xy ? m->d_prev : nullptr;
+    A.prev_out = prev_matched_xy ? m->d_prev_out : nullptr;
+    A.min_x = f2->min_x;
+    A.max_x = f2->max_x;
+    A.min_y = f2->min_y;
+    A.max_y = f2->max_y;
+    A.window = window_size;
+    A.nnratio = nnratio;
+    A.check_ori = check_orientation;
+    A.matches12 = m->d_m12;
+    A.nmatches = m->d_nm;
+    A.bin_scratch = m->d_bins;
+    int rc = launch_match(A, 1, m->stream);
+    if (rc) return rc;
+    MCHK(hipMemcpyAsync(matches12, m->d_m12, (size_t)f1->n * 4, hipMemcpyDeviceToHost, m->stream));
+    MCHK(hipMemcpyAsync(n_matches, m->d_nm, 4, hipMemcpyDeviceToHost, m->stream));
+    if (prev_matched_xy)
+        MCHK(hipMemcpyAsync(prev_matched_xy, m->d_prev_out, (size_t)f1->n * 8, hipMemcpyDeviceToHost, m->stream));
+    MCHK(hipStreamSynchronize(m->stream));
+    return ORB_OK;
+}
+
+extern "C" int orb_match_batch_device(OrbMatcher *m, const OrbKeyPoint *d_kps, const uint8_t *d_desc,
+                                      const int32_t *d_counts, int cap, const int32_t *d_pair_a, const int32_t *d_pair_b,
+                                      int n_pairs, float min_x, float max_x, float min_y, float max_y, int window_size,
+                                      float nnratio, int check_orientation, int32_t *d_matches12, int32_t *d_nmatches,
+                                      void *stream) {
+    if (!m || !d_kps || !d_desc || !d_counts || !d_pair_a || !d_pair_b || !d_matches12 || !d_nmatches || n_pairs <= 0 ||
+        cap <= 0)
+        return ORB_E_INVALID;
+    if (n_pairs > m->max_pairs || cap > m->max_kp) return ORB_E_CAPACITY;
+    MCHK(hipSetDevice(m->device));
+    MatchArgs A{};
+    A.kps = d_kps;
+    A.desc = d_desc;
+    A.counts = d_counts;
+    A.cap = cap;
+    A.pair_a = d_pair_a;
+    A.pair_b = d_pair_b;
+    A.prev_xy = nullptr;
+    A.prev_out = nullptr;
+    A.min_x = min_x;
+    A.max_x = max_x;
+    A.min_y = min_y;
+    A.max_y = max_y;
+    A.window = window_size;
+    A.nnratio = nnratio;
+    A.check_ori = check_orientation;
+    A.matches12 = d_matches12;
+    A.nmatches = d_nmatches;
+    A.bin_scratch = m->d_bins;
+    return launch_match(A, n_pairs, stream ? (hipStream_t)stream : m->stream);
+}

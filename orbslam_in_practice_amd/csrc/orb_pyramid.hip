@@ -1,0 +1,158 @@
+/*
+ * orb_pyramid.hip -- scale pyramid and Gaussian blur for gfx950.
+ *
+ * Replaces ORBextractor::ComputePyramid (reference src/ORBextractor.cpp:1071-1096: cv::resize
+ * INTER_LINEAR level l-1 -> l) and the per-level cv::GaussianBlur(7x7, sigma 2, REFLECT_101) of
+ * operator() (:1045-1046).  Integer fixed-point arithmetic identical to the OpenCV 2.4/3.x CV_8U
+ * paths (11-bit bilinear coefficients; 8-bit Gaussian taps {18,34,49,55,49,34,18}), so results are
+ * bit-exact with the CPU restatement in oracle/orb_oracle.cpp.
+ *
+ * HBM-bound byte work: rows are read/written as coalesced 64..256-byte segments, the blur stages its
+ * (32+6)x(64+6) input tile and the horizontal pass in LDS.  The 19-px apron of mvImagePyramid is not
+ * stored on the device (no kernel reads it); orb_download_level() rebuilds it on request.
+ */
+#include "orb_common.h"
+
+struct TileMap {
+    int prefix[ORB_MAX_LEVELS + 1];
+    int tiles_x[ORB_MAX_LEVELS];
+};
+
+/* ---- level 0: copy the input frame into the pitch-aligned pyramid block ------------------------ */
+__global__ __launch_bounds__(256) void k_copy_level0(OrbGeom g, uint8_t *pyr, const uint8_t *imgs, int stride,
+                                                      int64_t frame_stride, int vec16) {
+    const int frame = blockIdx.z;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= g.h) return;
+    const uint8_t *src = imgs + (int64_t)frame * frame_stride + (int64_t)y * stride;
+    uint8_t *dst = level_ptr(pyr, g, frame, 0) + (int64_t)y * g.lv[0].pitch;
+    const int lane = threadIdx.x & 63;
+    if (vec16) {
+        for (int x = (blockIdx.x * 64 + lane) * 16; x < g.w; x += gridDim.x * 64 * 16) {
+            if (x + 16 <= g.w) {
+                *(uint4 *)(dst + x) = *(const uint4 *)(src + x);
+            } else {
+                for (int i = 0; x + i < g.w; i++) dst[x + i] = src[x + i];
+            }
+        }
+    } else {
+        for (int x = (blockIdx.x * 64 + lane) * 4; x < g.w; x += gridDim.x * 64 * 4) {
+            uint32_t v = 0;
+            for (int i = 0; i < 4; i++)
+                if (x + i < g.w) v |= (uint32_t)src[x + i] << (8 * i);
+            *(uint32_t *)(dst + x) = v; /* pitch is a multiple of 64: the tail store stays inside the row */
+        }
+    }
+}
+
+/* ---- level l from level l-1, cv::resize INTER_LINEAR fixed point -------------------------------- */
+__global__ __launch_bounds__(256) void k_resize(OrbGeom g, uint8_t *pyr, const int32_t *tab_i, const int16_t *tab_c,
+                                                 int level) {
+    const LevelGeom &L = g.lv[level];
+    const LevelGeom &S = g.lv[level - 1];
+    const int frame = blockIdx.z;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    if (y >= L.h || x0 >= L.w) return;
+    const uint8_t *src = level_ptr(pyr, g, frame, level - 1);
+    uint8_t *dst = level_ptr(pyr, g, frame, level) + (int64_t)y * L.pitch;
+    const int32_t *xofs = tab_i + L.xofs_off;
+    const int32_t *yofs = tab_i + L.yofs_off;
+    const int16_t *ialpha = tab_c + 2 * L.xofs_off;
+    const int16_t *ibeta = tab_c + 2 * L.yofs_off;
+    int sy = yofs[y];
+    int sy0 = min(max(sy, 0), S.h - 1), sy1 = min(max(sy + 1, 0), S.h - 1);
+    const uint8_t *r0 = src + (int64_t)sy0 * S.pitch;
+    const uint8_t *r1 = src + (int64_t)sy1 * S.pitch;
+    const int b0 = ibeta[2 * y], b1 = ibeta[2 * y + 1];
+    uint32_t packed = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int x = x0 + i;
+        if (x < L.w) {
+            int sx = xofs[x];
+            int sx1 = min(sx + 1, S.w - 1);
+            int a0 = ialpha[2 * x], a1 = ialpha[2 * x + 1];
+            int h0 = r0[sx] * a0 + r0[sx1] * a1;
+            int h1 = r1[sx] * a0 + r1[sx1] * a1;
+            int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            packed |= (uint32_t)(v & 0xFF) << (8 * i);
+        }
+    }
+    *(uint32_t *)(dst + x0) = packed;
+}
+
+/* ---- 7x7 Gaussian blur, all levels in one launch -------------------------------------------------- */
+#define BL_TW 64
+#define BL_TH 32
+__device__ __forceinline__ int reflect101(int p, int n) {
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * (n - 1) - p;
+    return p;
+}
+
+__global__ __launch_bounds__(256) void k_blur(OrbGeom g, const uint8_t *pyr, uint8_t *blur, TileMap tm) {
+    __shared__ uint8_t s_in[BL_TH + 6][BL_TW + 8];
+    __shared__ uint16_t s_h[BL_TH + 6][BL_TW];
+    int level = 0;
+    while (level + 1 < g.nlevels && (int)blockIdx.x >= tm.prefix[level + 1]) level++;
+    const LevelGeom &L = g.lv[level];
+    const int t = blockIdx.x - tm.prefix[level];
+    const int tx0 = (t % tm.tiles_x[level]) * BL_TW, ty0 = (t / tm.tiles_x[level]) * BL_TH;
+    const int frame = blockIdx.y;
+    const uint8_t *src = level_ptr(pyr, g, frame, level);
+    uint8_t *dst = level_ptr(blur, g, frame, level);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < (BL_TH + 6) * (BL_TW + 6); i += 256) {
+        int r = i / (BL_TW + 6), c = i - r * (BL_TW + 6);
+        int y = reflect101(ty0 + r - 3, L.h), x = reflect101(tx0 + c - 3, L.w);
+        s_in[r][c] = src[(int64_t)y * L.pitch + x];
+    }
+    __syncthreads();
+    for (int i = tid; i < (BL_TH + 6) * BL_TW; i += 256) {
+        int r = i >> 6, c = i & 63;
+        const uint8_t *p = &s_in[r][c];
+        int s = 18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3];
+        s_h[r][c] = (uint16_t)s; /* <= 255*257 = 65535 */
+    }
+    __syncthreads();
+    const int c = tid & 63, rq = tid >> 6;
+    const int x = tx0 + c;
+    if (x >= L.w) return;
+#pragma unroll
+    for (int k = 0; k < BL_TH / 4; k++) {
+        int r = rq * (BL_TH / 4) + k;
+        int y = ty0 + r;
+        if (y >= L.h) break;
+        int s = 18 * ((int)s_h[r][c] + s_h[r + 6][c]) + 34 * ((int)s_h[r + 1][c] + s_h[r + 5][c]) +
+                49 * ((int)s_h[r + 2][c] + s_h[r + 4][c]) + 55 * (int)s_h[r + 3][c];
+        int v = (s + (1 << 15)) >> 16;
+        dst[(int64_t)y * L.pitch + x] = (uint8_t)(v > 255 ? 255 : v);
+    }
+}
+
+hipError_t launch_pyramid(const OrbGeom &g, const OrbBuffers &b, const uint8_t *d_imgs, int stride,
+                          int64_t frame_stride, int n_frames, hipStream_t st) {
+    int vec16 = (((uintptr_t)d_imgs | (uintptr_t)stride | (uintptr_t)frame_stride) & 15) == 0;
+    dim3 grid0((g.w + 1023) / 1024, (g.h + 3) / 4, n_frames);
+    hipLaunchKernelGGL(k_copy_level0, grid0, dim3(256), 0, st, g, b.pyr, d_imgs, stride, frame_stride, vec16);
+    for (int l = 1; l < g.nlevels; l++) {
+        dim3 grid((g.lv[l].w + 255) / 256, (g.lv[l].h + 3) / 4, n_frames);
+        hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, g, b.pyr, b.tab_i, b.tab_c, l);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_blur(const OrbGeom &g, const OrbBuffers &b, int n_frames, hipStream_t st) {
+    TileMap tm;
+    tm.prefix[0] = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+        tm.tiles_x[l] = (g.lv[l].w + BL_TW - 1) / BL_TW;
+        int ty = (g.lv[l].h + BL_TH - 1) / BL_TH;
+        tm.prefix[l + 1] = tm.prefix[l] + tm.tiles_x[l] * ty;
+    }
+    for (int l = g.nlevels; l < ORB_MAX_LEVELS; l++) tm.prefix[l + 1] = tm.prefix[g.nlevels];
+    dim3 grid(tm.prefix[g.nlevels], n_frames);
+    hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, st, g, (const uint8_t *)b.pyr, b.blur, tm);
+    return hipGetLastError();
+}
