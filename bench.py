@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- hot-path throughput of the MI355X ORB front-end (BASELINE.json configs[1]).
+
+One "step" = one pass of the hot path over one batch: ORB extraction (8-level pyramid, FAST cells,
+quadtree, blur, rBRIEF) of B synthetic 640x480 frames per GPU + brute-force Hamming matching of the
+B consecutive frame pairs (k, k+1).  Inputs are resident in HBM before the timed region starts;
+outputs stay in HBM.  With N > 1 GPUs every rank processes its own B frames (weak scaling) and the
+per-frame feature slabs are exchanged with ONE round of RCCL all-gathers so that the last local frame
+is matched against the first frame of the next rank.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (see the driver contract) with `roofline` (dominant stage, live HIP-event
+timing) and, at N == 1, `cpu_baseline` (the CPU oracle -- a port of the reference path -- timed on a
+bounded sample on this box's host cores).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H = 640, 480
+NFEATURES, SCALE, NLEVELS, INI_TH, MIN_TH = 1000, 1.2, 8, 20, 7
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def algorithmic_bytes_per_frame(level_sizes, n_kp):
+    """per-stage ALGORITHMIC bytes for one frame (aprons excluded)."""
+    ws, hs = level_sizes
+    P = int(sum(int(a) * int(b) for a, b in zip(ws, hs)))
+    return {
+        "pyramid": W * H + P,               # input read + pyramid write
+        "fast": P,                          # every level read once
+        "quadtree": 0,
+        "blur": 2 * P,                      # level read + blurred level write
+        "describe": (749 + 512 + 60) * n_kp,  # orientation gather + descriptor gather + 28 B kp + 32 B desc
+        "match": 32 * 2 * n_kp + 8 * n_kp,  # both descriptor sets + result
+    }
+
+
+def cpu_baseline(n_frames):
+    """the CPU oracle (oracle/, a port of the reference's single-threaded path) on a bounded sample"""
+    from oracle import oracle as orc
+    from orbslam_in_practice_amd import synth
+    frames = synth.make_stream(12345, n_frames + 1, W, H)
+    o = orc.OrbOracle(NFEATURES, SCALE, NLEVELS, INI_TH, MIN_TH)
+    o.extract(frames[0])  # warm-up
+    t0 = time.perf_counter()
+    feats = [o.extract(f) for f in frames]
+    bounds = (0.0, float(W), 0.0, float(H))
+    for k in range(n_frames):
+        orc.search_for_initialization(feats[k][0], feats[k][1], feats[k + 1][0], feats[k + 1][1], bounds, None, -1, 0.9,
+                                      True, 0)
+    dt = time.perf_counter() - t0
+    return {"value": round(n_frames / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d frames 640x480 extract + brute-force match(k,k+1), oracle/ (C++ -O2, 1 thread), %.1f s"
+                      % (n_frames, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--cpu-frames", type=int, default=48, help="CPU baseline sample size (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the product has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import orbslam_in_practice_amd as oa
+    from orbslam_in_practice_amd import synth
+
+    B = args.batch
+    ext = oa.ORBextractor(NFEATURES, SCALE, NLEVELS, INI_TH, MIN_TH, max_w=W, max_h=H, max_batch=B,
+                          device=local_rank)
+    cap = ext.cap
+    matcher = oa.ORBmatcher(0.9, True, max_keypoints=cap, max_pairs=B, device=local_rank)
+
+    frames = synth.make_stream(1000 + rank, B, W, H)
+    d_imgs = torch.from_numpy(frames).to(dev)
+    nG = world * B  # frames visible to the matcher after the exchange
+    d_kps = torch.zeros((nG, cap, 28), dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros((nG, cap, 32), dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros((nG,), dtype=torch.int32, device=dev)
+    lo = rank * B
+    k_loc, d_loc, c_loc = d_kps[lo:lo + B], d_desc[lo:lo + B], d_cnt[lo:lo + B]
+    pa = torch.arange(lo, lo + B, dtype=torch.int32, device=dev)
+    pb = torch.remainder(pa + 1, nG).to(torch.int32) if world > 1 else \
+        torch.remainder(torch.arange(1, B + 1, dtype=torch.int32, device=dev), B).to(torch.int32)
+    d_m12 = torch.full((B, cap), -1, dtype=torch.int32, device=dev)
+    d_nm = torch.zeros((B,), dtype=torch.int32, device=dev)
+    bounds = (0.0, float(W), 0.0, float(H))
+
+    stream = torch.cuda.Stream(device=dev)
+    sp = C.c_void_p(stream.cuda_stream)
+
+    def step():
+        ext.extract_batch_device(d_imgs.data_ptr(), B, W, H, W, W * H, k_loc.data_ptr(), d_loc.data_ptr(), cap,
+                                 c_loc.data_ptr(), sp)
+        if world > 1:  # the one exchange step of the path: fixed-capacity feature slabs over xGMI
+            dist.all_gather_into_tensor(d_kps.view(-1), k_loc.reshape(-1))
+            dist.all_gather_into_tensor(d_desc.view(-1), d_loc.reshape(-1))
+            dist.all_gather_into_tensor(d_cnt, c_loc)
+        matcher.match_batch_device(d_kps.data_ptr(), d_desc.data_ptr(), d_cnt.data_ptr(), cap, pa.data_ptr(),
+                                   pb.data_ptr(), B, bounds, -1, d_m12.data_ptr(), d_nm.data_ptr(), sp)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    L = oa._lib.lib()
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        oa._lib.check(L.orb_set_profiling(ext._h, 1))
+        oa._lib.check(L.orb_matcher_set_profiling(matcher._m, 1))
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # live per-stage durations (HIP events on the launch stream, averaged over the timed steps)
+    ms5 = (C.c_float * 5)()
+    oa._lib.check(L.orb_get_stage_ms(ext._h, ms5))
+    mm = C.c_float(0)
+    oa._lib.check(L.orb_matcher_get_ms(matcher._m, C.byref(mm)))
+    stage_ms = dict(zip(["pyramid", "fast", "quadtree", "blur", "describe"], [float(v) for v in ms5]))
+    stage_ms["match"] = float(mm.value)
+    counts = c_loc.cpu().numpy()
+    nmatch = d_nm.cpu().numpy()
+    n_kp = float(counts.mean())
+
+    if rank == 0:
+        fps = world * B * args.steps / elapsed
+        ab = algorithmic_bytes_per_frame(ext.level_sizes(W, H), n_kp)
+        timed = {k: v for k, v in stage_ms.items() if ab.get(k, 0) > 0}
+        dom = max(timed, key=timed.get)
+        achieved = ab[dom] * B / (stage_ms[dom] * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "frames/s ORB extract+match @640x480", "value": round(fps, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "configs[1]: ORB extract (8 levels, 1000 features, FAST 20/7) + brute-force "
+                                   "Hamming match of consecutive frames, 640x480 stream",
+                       "frames_per_gpu_per_step": B, "pairs_per_gpu_per_step": B,
+                       "keypoints_per_frame": round(n_kp, 1), "matches_per_pair": round(float(nmatch.mean()), 1),
+                       "exchange": "rccl all_gather of kp/desc/count slabs" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": int(ab[dom] * B),
+                         "avg_launch_ms": round(stage_ms[dom], 4)},
+            "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+        }
+        if world == 1 and args.cpu_frames > 0:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_frames)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -95,6 +95,11 @@ int orb_download_level(OrbExtractor *h, int frame, int level, int blurred, uint8
 /* FAST candidates of (frame, level) before the quadtree, in the reference's order
  * (src/ORBextractor.cpp:745-786); returns the count through n_out even if cap is too small. */
 int orb_download_candidates(OrbExtractor *h, int frame, int level, OrbKeyPoint *out, int cap, int32_t *n_out);
+/* measurement hooks: with profiling enabled every orb_extract_batch_device call records HIP events on
+ * the launch stream between its stages; orb_get_stage_ms waits for the last call and returns the five
+ * stage durations in ms: {pyramid (copy + resizes), FAST cells, quadtree, blur, describe}. */
+int orb_set_profiling(OrbExtractor *h, int enable);
+int orb_get_stage_ms(OrbExtractor *h, float *ms5);
 /* wait for everything enqueued on the handle's stream */
 int orb_synchronize(OrbExtractor *h);
 /* the handle's hipStream_t */
@@ -110,6 +115,9 @@ typedef struct OrbMatcher OrbMatcher; /* opaque: device buffers + stream for mat
 int orb_matcher_create(int max_keypoints, int max_pairs, int device_id, OrbMatcher **out);
 void orb_matcher_destroy(OrbMatcher *m);
 void *orb_matcher_stream(OrbMatcher *m);
+/* same hook for the matcher: duration in ms of the last orb_match_batch_device kernel */
+int orb_matcher_set_profiling(OrbMatcher *m, int enable);
+int orb_matcher_get_ms(OrbMatcher *m, float *ms);
 int orb_matcher_synchronize(OrbMatcher *m);
 
 /* brute-force Hamming 2-NN (north_star): for every row of d1[n1*32] the best and second

@@ -82,6 +82,10 @@ struct OrbExtractor {
     int32_t *d_counts = nullptr, *h_counts = nullptr;
     int out_cap = 0;
     int last_frames = 0;
+    bool profile = false;
+    static const int kProfRing = 64;
+    hipEvent_t ev[64][6] = {};
+    long prof_calls = 0;
 };
 
 /* reference src/ORBextractor.cpp:360-420 */
@@ -407,6 +411,9 @@ extern "C" void orb_destroy(OrbExtractor *h) {
     if (h->h_kps) (void)hipHostFree(h->h_kps);
     if (h->h_desc) (void)hipHostFree(h->h_desc);
     if (h->h_counts) (void)hipHostFree(h->h_counts);
+    for (int r = 0; r < OrbExtractor::kProfRing; r++)
+        for (int i = 0; i < 6; i++)
+            if (h->ev[r][i]) (void)hipEventDestroy(h->ev[r][i]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -437,6 +444,33 @@ extern "C" int orb_get_level_sizes(const OrbExtractor *h, int w, int hgt, int32_
     }
     return ORB_OK;
 }
+extern "C" int orb_set_profiling(OrbExtractor *h, int enable) {
+    if (!h) return ORB_E_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    if (enable && !h->ev[0][0])
+        for (int r = 0; r < OrbExtractor::kProfRing; r++)
+            for (int i = 0; i < 6; i++) HIPCHK(hipEventCreate(&h->ev[r][i]));
+    h->profile = enable != 0;
+    h->prof_calls = 0;
+    return ORB_OK;
+}
+/* average stage durations over the (at most 64 most recent) calls recorded since profiling was enabled */
+extern "C" int orb_get_stage_ms(OrbExtractor *h, float *ms5) {
+    if (!h || !ms5 || !h->ev[0][0] || h->prof_calls == 0) return ORB_E_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    const int n = (int)std::min<long>(h->prof_calls, OrbExtractor::kProfRing);
+    for (int i = 0; i < 5; i++) ms5[i] = 0.f;
+    for (int r = 0; r < n; r++) {
+        HIPCHK(hipEventSynchronize(h->ev[r][5]));
+        for (int i = 0; i < 5; i++) {
+            float t = 0.f;
+            HIPCHK(hipEventElapsedTime(&t, h->ev[r][i], h->ev[r][i + 1]));
+            ms5[i] += t / n;
+        }
+    }
+    h->prof_calls = 0;
+    return ORB_OK;
+}
 extern "C" void *orb_stream(OrbExtractor *h) { return h ? (void *)h->stream : nullptr; }
 extern "C" int orb_synchronize(OrbExtractor *h) {
     if (!h) return ORB_E_INVALID;
@@ -462,11 +496,20 @@ extern "C" int orb_extract_batch_device(OrbExtractor *h, const uint8_t *d_imgs, 
     if ((rc = ensure_buffers(h, n_frames))) return rc;
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     const OrbGeom &g = h->geom;
+    const bool prof = h->profile;
+    hipEvent_t *ev = h->ev[h->prof_calls % OrbExtractor::kProfRing];
+    if (prof) HIPCHK(hipEventRecord(ev[0], st));
     HIPCHK(launch_pyramid(g, h->buf, d_imgs, stride, frame_stride, n_frames, st));
+    if (prof) HIPCHK(hipEventRecord(ev[1], st));
     HIPCHK(launch_fast(g, h->buf, n_frames, st));
+    if (prof) HIPCHK(hipEventRecord(ev[2], st));
     HIPCHK(launch_quadtree(g, h->buf, n_frames, st));
+    if (prof) HIPCHK(hipEventRecord(ev[3], st));
     HIPCHK(launch_blur(g, h->buf, n_frames, st));
+    if (prof) HIPCHK(hipEventRecord(ev[4], st));
     HIPCHK(launch_describe(g, h->buf, n_frames, d_kps, d_desc, cap, d_counts, st));
+    if (prof) HIPCHK(hipEventRecord(ev[5], st));
+    if (prof) h->prof_calls++;
     h->last_frames = n_frames;
     return ORB_OK;
 }

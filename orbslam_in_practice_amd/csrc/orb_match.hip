@@ -287,6 +287,10 @@ struct OrbMatcher {
     uint8_t *d_bins = nullptr;    /* [max_pairs][max_kp] */
     int32_t *d_idx = nullptr;
     uint16_t *d_best = nullptr, *d_second = nullptr;
+    bool profile = false;
+    static const int kProfRing = 64;
+    hipEvent_t ev[64][2] = {};
+    long prof_calls = 0;
 };
 
 extern "C" int orb_matcher_create(int max_keypoints, int max_pairs, int device_id, OrbMatcher **out) {
@@ -330,11 +334,39 @@ extern "C" void orb_matcher_destroy(OrbMatcher *m) {
     (void)hipFree(m->d_idx);
     (void)hipFree(m->d_best);
     (void)hipFree(m->d_second);
+    for (int r = 0; r < OrbMatcher::kProfRing; r++)
+        for (int i = 0; i < 2; i++)
+            if (m->ev[r][i]) (void)hipEventDestroy(m->ev[r][i]);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
 
 extern "C" void *orb_matcher_stream(OrbMatcher *m) { return m ? (void *)m->stream : nullptr; }
+extern "C" int orb_matcher_set_profiling(OrbMatcher *m, int enable) {
+    if (!m) return ORB_E_INVALID;
+    MCHK(hipSetDevice(m->device));
+    if (enable && !m->ev[0][0])
+        for (int r = 0; r < OrbMatcher::kProfRing; r++)
+            for (int i = 0; i < 2; i++) MCHK(hipEventCreate(&m->ev[r][i]));
+    m->profile = enable != 0;
+    m->prof_calls = 0;
+    return ORB_OK;
+}
+/* average kernel duration over the (at most 64 most recent) batch calls since profiling was enabled */
+extern "C" int orb_matcher_get_ms(OrbMatcher *m, float *ms) {
+    if (!m || !ms || !m->ev[0][0] || m->prof_calls == 0) return ORB_E_INVALID;
+    MCHK(hipSetDevice(m->device));
+    const int n = (int)(m->prof_calls < OrbMatcher::kProfRing ? m->prof_calls : OrbMatcher::kProfRing);
+    *ms = 0.f;
+    for (int r = 0; r < n; r++) {
+        float t = 0.f;
+        MCHK(hipEventSynchronize(m->ev[r][1]));
+        MCHK(hipEventElapsedTime(&t, m->ev[r][0], m->ev[r][1]));
+        *ms += t / n;
+    }
+    m->prof_calls = 0;
+    return ORB_OK;
+}
 extern "C" int orb_matcher_synchronize(OrbMatcher *m) {
     if (!m) return ORB_E_INVALID;
     MCHK(hipSetDevice(m->device));
@@ -500,5 +532,13 @@ extern "C" int orb_match_batch_device(OrbMatcher *m, const OrbKeyPoint *d_kps, c
     A.matches12 = d_matches12;
     A.nmatches = d_nmatches;
     A.bin_scratch = m->d_bins;
-    return launch_match(A, n_pairs, stream ? (hipStream_t)stream : m->stream);
+    hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+    hipEvent_t *ev = m->ev[m->prof_calls % OrbMatcher::kProfRing];
+    if (m->profile) MCHK(hipEventRecord(ev[0], st));
+    int rc = launch_match(A, n_pairs, st);
+    if (m->profile) {
+        MCHK(hipEventRecord(ev[1], st));
+        m->prof_calls++;
+    }
+    return rc;
 }
