@@ -86,6 +86,37 @@ int orc_search_for_initialization(const OrcFrameView *f1, const OrcFrameView *f2
 void orc_compute_three_maxima(const int32_t *histo_sizes, int L, int32_t *ind1, int32_t *ind2,
                               int32_t *ind3);
 
+/* ---- bundle adjustment (a13..a15); same layout as BAProblem / BAResult of include/orbslam_amd.h ---- */
+typedef struct OrcBAProblem {
+    int32_t n_cams, n_points, n_obs;
+    const double *poses;
+    const uint8_t *fixed;
+    const double *points;
+    const double *obs;
+    const int32_t *cam_idx;
+    const int32_t *pt_idx;
+    const double *inv_sigma2;
+    double fx, fy, cx, cy;
+    double huber_delta;
+    int32_t n_rounds;
+    int32_t rounds[4];
+    double chi2_threshold;
+    int32_t drop_robust_after;
+    volatile const uint8_t *stop;
+} OrcBAProblem;
+
+typedef struct OrcBAResult {
+    double *poses;
+    double *points;
+    uint8_t *outlier;
+    double chi2_initial, chi2_final;
+    int32_t iterations, lin_solves;
+} OrcBAResult;
+
+int orc_ba_solve(const OrcBAProblem *p, OrcBAResult *r);
+int orc_pose_optimization(double *pose7, const double *xw, const double *obs, const double *inv_sigma2, int n,
+                          double fx, double fy, double cx, double cy, uint8_t *outlier, int32_t *n_inliers);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,12 +76,27 @@ def lib():
     return _lib
 
 
+class BAProblem(C.Structure):
+    _fields_ = [("n_cams", C.c_int32), ("n_points", C.c_int32), ("n_obs", C.c_int32),
+                ("poses", C.c_void_p), ("fixed", C.c_void_p), ("points", C.c_void_p), ("obs", C.c_void_p),
+                ("cam_idx", C.c_void_p), ("pt_idx", C.c_void_p), ("inv_sigma2", C.c_void_p),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("huber_delta", C.c_double), ("n_rounds", C.c_int32), ("rounds", C.c_int32 * 4),
+                ("chi2_threshold", C.c_double), ("drop_robust_after", C.c_int32), ("stop", C.c_void_p)]
+
+
+class BAResult(C.Structure):
+    _fields_ = [("poses", C.c_void_p), ("points", C.c_void_p), ("outlier", C.c_void_p),
+                ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("iterations", C.c_int32),
+                ("lin_solves", C.c_int32)]
+
+
 def _register_ba(L):
-    if hasattr(L, "orc_ba_solve"):
-        L.orc_ba_solve.argtypes = [C.c_void_p, C.c_void_p]
-        L.orc_ba_solve.restype = C.c_int
-    if hasattr(L, "orc_pose_optimization"):
-        L.orc_pose_optimization.restype = C.c_int
+    L.orc_ba_solve.argtypes = [C.POINTER(BAProblem), C.POINTER(BAResult)]
+    L.orc_ba_solve.restype = C.c_int
+    L.orc_pose_optimization.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double,
+                                        C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+    L.orc_pose_optimization.restype = C.c_int
 
 
 def _p(a):
@@ -260,3 +275,56 @@ def compute_three_maxima(sizes):
     a, b, c = C.c_int32(-1), C.c_int32(-1), C.c_int32(-1)
     lib().orc_compute_three_maxima(_p(sizes), len(sizes), C.byref(a), C.byref(b), C.byref(c))
     return a.value, b.value, c.value
+
+
+HUBER_2D = float(np.sqrt(5.99))  # src/Optimizer.cpp:61
+
+
+def fill_ba_problem(P, w, rounds, robust=True, chi2_threshold=5.991, drop_robust_after=0, keep=None):
+    """fill a BAProblem-shaped ctypes struct from a synth.make_ba_window() dict; returns the arrays that
+    must stay alive"""
+    arrs = dict(poses=np.ascontiguousarray(w["poses"], np.float64), fixed=np.ascontiguousarray(w["fixed"], np.uint8),
+                points=np.ascontiguousarray(w["points"], np.float64), obs=np.ascontiguousarray(w["obs"], np.float64),
+                cam_idx=np.ascontiguousarray(w["cam_idx"], np.int32), pt_idx=np.ascontiguousarray(w["pt_idx"], np.int32),
+                inv_sigma2=np.ascontiguousarray(w["inv_sigma2"], np.float64))
+    P.n_cams, P.n_points, P.n_obs = len(arrs["poses"]), len(arrs["points"]), len(arrs["obs"])
+    for k, v in arrs.items():
+        setattr(P, k, v.ctypes.data)
+    P.fx, P.fy, P.cx, P.cy = w["fx"], w["fy"], w["cx"], w["cy"]
+    P.huber_delta = HUBER_2D if robust else 0.0
+    P.n_rounds = len(rounds)
+    for i, r in enumerate(rounds):
+        P.rounds[i] = int(r)
+    P.chi2_threshold = chi2_threshold
+    P.drop_robust_after = drop_robust_after
+    P.stop = None
+    return arrs
+
+
+def ba_solve(w, rounds=(5, 10), robust=True, chi2_threshold=5.991, drop_robust_after=0):
+    """oracle BA on a synth.make_ba_window() dict.  rounds=(5,10): local BA schedule (a14);
+    rounds=(20,): global BA (a13)."""
+    P, R = BAProblem(), BAResult()
+    keep = fill_ba_problem(P, w, rounds, robust, chi2_threshold, drop_robust_after)
+    poses = np.zeros((P.n_cams, 7), np.float64)
+    points = np.zeros((P.n_points, 3), np.float64)
+    outlier = np.zeros(P.n_obs, np.uint8)
+    R.poses, R.points, R.outlier = poses.ctypes.data, points.ctypes.data, outlier.ctypes.data
+    rc = lib().orc_ba_solve(C.byref(P), C.byref(R))
+    assert rc == 0
+    del keep
+    return dict(poses=poses, points=points, outlier=outlier, chi2_initial=R.chi2_initial, chi2_final=R.chi2_final,
+                iterations=R.iterations, lin_solves=R.lin_solves)
+
+
+def pose_optimization(pose, xw, obs, inv_sigma2, fx, fy, cx, cy):
+    pose = np.ascontiguousarray(pose, np.float64).copy()
+    xw = np.ascontiguousarray(xw, np.float64)
+    obs = np.ascontiguousarray(obs, np.float64)
+    inv_sigma2 = np.ascontiguousarray(inv_sigma2, np.float64)
+    n = len(xw)
+    outlier = np.zeros(max(n, 1), np.uint8)
+    ninl = C.c_int32(0)
+    lib().orc_pose_optimization(_p(pose), _p(xw), _p(obs), _p(inv_sigma2), n, fx, fy, cx, cy, _p(outlier),
+                                C.byref(ninl))
+    return pose, outlier[:n], ninl.value

@@ -8,3 +8,4 @@ matcher or solver without the HIP library / a HIP device raises.
 from ._lib import KP_DTYPE, OrbError, build  # noqa: F401
 from .extractor import ORBextractor  # noqa: F401
 from .matcher import FrameFeatures, ORBmatcher  # noqa: F401
+from .optimizer import Optimizer  # noqa: F401

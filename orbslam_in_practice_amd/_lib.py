@@ -119,9 +119,6 @@ def lib():
     L.orb_match_init.argtypes = [vp, C.POINTER(OrbFrameView), C.POINTER(OrbFrameView), vp, vp, i32, f32, i32, vp]
     L.orb_match_batch_device.argtypes = [vp, vp, vp, vp, i32, vp, vp, i32, f32, f32, f32, f32, i32, f32, i32, vp,
                                          vp, vp]
-    if not hasattr(L, 'ba_create'):  # TEMP until ba_api.hip lands
-        _lib = L
-        return L
     L.ba_create.argtypes = [i32, i32, i32, i32, i32, C.POINTER(vp)]
     L.ba_destroy.argtypes = [vp]
     L.ba_destroy.restype = None

@@ -1,0 +1,1264 @@
+/*
+ * ba_api.hip -- bundle adjustment on gfx950: Optimizer::BundleAdjustment / LocalBundleAdjustment /
+ * PoseOptimization numerical core behind ba_solve*() (include/orbslam_amd.h).
+ *
+ * What the reference does (src/Optimizer.cpp:23-129): build a g2o graph (SE3 pose vertices, XYZ point
+ * vertices marginalised, EdgeSE3ProjectXYZ with Huber kernel) and run g2o's Levenberg-Marquardt with a
+ * Schur-complement block solver.  Here the same algorithm runs on the device, all in f64:
+ *
+ *   ONE 512-thread workgroup per BA window, one kernel launch per LM iteration for the whole batch of
+ *   windows (the host only checks pbStopFlag between launches and never touches per-iteration data).
+ *   Inside the launch, per window:
+ *     residuals + robust chi2 -> per-edge 2x3 / 2x6 Jacobian blocks -> Hll (3x3, one thread per point,
+ *     its edges are contiguous), W = Hpl blocks (6x3 per edge), Hpp (6x6, one wavefront per camera with
+ *     shuffle reductions) -> LM trials: Dinv = (Hll + lambda I)^-1, Y = W Dinv, block-sparse reduced
+ *     camera system S = Hpp + lambda I - sum Y W^T (one wavefront per non-zero 6x6 block, fixed
+ *     contribution order: no atomics, bit-reproducible), g = bp - sum Y bl -> PCG with block-Jacobi
+ *     preconditioner (p, r in LDS, row-per-thread block-CSR product) -> back-substitution -> exp-map
+ *     update -> trial chi2 -> gain ratio / lambda update exactly as OptimizationAlgorithmLevenberg.
+ *
+ * MFMA note: on gfx950 the f64 matrix rate equals the f64 vector rate (78.6 TFLOP/s both) and the
+ * reduced system product is a matrix-VECTOR product served from L2, so v_mfma_f64 buys nothing here;
+ * the S p product stays on the vector ALU (BA section).
+ *
+ * No CPU fallback: the host code below only sorts indices and moves buffers.
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/orbslam_amd.h"
+
+#define BA_T 512
+#define BA_W (BA_T / 64)
+#define BA_MAX_N 1536 /* reduced system size (6 * free cameras) that fits the LDS vectors */
+
+static thread_local std::string b_err;
+#define BCHK(expr)                                                          \
+    do {                                                                    \
+        hipError_t _e = (expr);                                             \
+        if (_e != hipSuccess) {                                             \
+            b_err = std::string(#expr) + ": " + hipGetErrorString(_e);      \
+            return ORB_E_HIP;                                               \
+        }                                                                   \
+    } while (0)
+
+/* per-window descriptor: element offsets into the batch buffers */
+struct BAWin {
+    int Nc, Np, E, Ncf, nnzb, pad;
+    double fx, fy, cx, cy, delta, chi2_thr;
+    /* doubles */
+    int64_t poses, poses_t, pts, pts_t, obs, info, err, err_t, W, Y, Hpp, bp, Hll, bl, Dinv, S, g, Minv, x, xl, st;
+    /* ints */
+    int64_t cam, pt, pt_start, cam_start, cam_edges, slot, blk_row, blk_col, blk_diag, con_start, con_e1, con_e2;
+    /* bytes */
+    int64_t flags; /* per edge: bit0 active, bit1 robust */
+};
+/* LM state (doubles at D[st + i]) */
+enum { ST_LAMBDA = 0, ST_NI, ST_CHI, ST_CHI0, ST_ITERS, ST_SOLVES, ST_TERM, ST_ROUND_IT, ST_HAVE_CHI0, ST_PCG_ITERS, ST_COUNT };
+
+struct BABufs {
+    double *D;
+    int32_t *I;
+    uint8_t *B;
+    const BAWin *wins;
+};
+
+/* ---------------------------------------------------------------------------------------------- */
+__device__ __forceinline__ void quat_to_R(const double *q, double R[9]) {
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w;
+    const double txx = tx * x, txy = ty * x, txz = tz * x;
+    const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+    R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+__device__ __forceinline__ void quat_normalize(double q[4]) {
+    if (q[0] < 0) {
+        q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3];
+    }
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+__device__ __forceinline__ void R_to_quat(const double R[9], double q[4]) {
+    double t = R[0] + R[4] + R[8];
+    if (t > 0) {
+        t = sqrt(t + 1.0);
+        q[0] = 0.5 * t;
+        t = 0.5 / t;
+        q[1] = (R[7] - R[5]) * t;
+        q[2] = (R[2] - R[6]) * t;
+        q[3] = (R[3] - R[1]) * t;
+    } else {
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > R[i * 4]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(R[i * 4] - R[j * 4] - R[k * 4] + 1.0);
+        double v[3];
+        v[i] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (R[k * 3 + j] - R[j * 3 + k]) * t;
+        v[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
+        v[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+        q[1] = v[0]; q[2] = v[1]; q[3] = v[2];
+    }
+}
+/* pose_out = SE3Quat::exp(u) * pose_in   (VertexSE3Expmap::oplusImpl) */
+__device__ void se3_exp_mul(const double u[6], const double *pin, double *pout) {
+    const double wx = u[0], wy = u[1], wz = u[2];
+    const double theta = sqrt(wx * wx + wy * wy + wz * wz);
+    const double O[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+    double O2[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) O2[i * 3 + j] = O[i * 3] * O[j] + O[i * 3 + 1] * O[3 + j] + O[i * 3 + 2] * O[6 + j];
+    double R[9], V[9];
+    if (theta < 0.00001) {
+        for (int i = 0; i < 9; i++) {
+            R[i] = (i % 4 == 0 ? 1.0 : 0.0) + O[i] + O2[i];
+            V[i] = R[i];
+        }
+    } else {
+        const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta),
+                     c = (theta - sin(theta)) / (theta * theta * theta);
+        for (int i = 0; i < 9; i++) {
+            R[i] = (i % 4 == 0 ? 1.0 : 0.0) + a * O[i] + b * O2[i];
+            V[i] = (i % 4 == 0 ? 1.0 : 0.0) + b * O[i] + c * O2[i];
+        }
+    }
+    double qe[4], te[3];
+    R_to_quat(R, qe);
+    quat_normalize(qe);
+    for (int i = 0; i < 3; i++) te[i] = V[i * 3] * u[3] + V[i * 3 + 1] * u[4] + V[i * 3 + 2] * u[5];
+    double RE[9];
+    quat_to_R(qe, RE);
+    const double *qi = pin, *ti = pin + 4;
+    double qo[4];
+    qo[0] = qe[0] * qi[0] - qe[1] * qi[1] - qe[2] * qi[2] - qe[3] * qi[3];
+    qo[1] = qe[0] * qi[1] + qe[1] * qi[0] + qe[2] * qi[3] - qe[3] * qi[2];
+    qo[2] = qe[0] * qi[2] - qe[1] * qi[3] + qe[2] * qi[0] + qe[3] * qi[1];
+    qo[3] = qe[0] * qi[3] + qe[1] * qi[2] - qe[2] * qi[1] + qe[3] * qi[0];
+    quat_normalize(qo);
+    for (int i = 0; i < 4; i++) pout[i] = qo[i];
+    for (int i = 0; i < 3; i++) pout[4 + i] = te[i] + RE[i * 3] * ti[0] + RE[i * 3 + 1] * ti[1] + RE[i * 3 + 2] * ti[2];
+}
+__device__ __forceinline__ void project_err(const double *pose, const double *X, const double *ob, double fx, double fy,
+                                            double cx, double cy, double e[2], double pc[3]) {
+    double R[9];
+    quat_to_R(pose, R);
+    pc[0] = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + pose[4];
+    pc[1] = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + pose[5];
+    pc[2] = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + pose[6];
+    e[0] = ob[0] - (pc[0] / pc[2] * fx + cx);
+    e[1] = ob[1] - (pc[1] / pc[2] * fy + cy);
+}
+__device__ __forceinline__ double huber_rho0(double e, double delta) {
+    const double d2 = delta * delta;
+    return e <= d2 ? e : 2 * sqrt(e) * delta - d2;
+}
+__device__ __forceinline__ double huber_w(double e, double delta) {
+    const double d2 = delta * delta;
+    return e <= d2 ? 1.0 : delta / sqrt(e);
+}
+/* EdgeSE3ProjectXYZ::linearizeOplus: Ji = d e/d point (2x3), Jj = d e/d pose (2x6) */
+__device__ __forceinline__ void jacobians(const double *pose, const double pc[3], double fx, double fy, double Ji[6],
+                                          double Jj[12]) {
+    double R[9];
+    quat_to_R(pose, R);
+    const double x = pc[0], y = pc[1], z = pc[2], z_2 = z * z;
+    const double t0 = fx, t2 = -x / z * fx, t4 = fy, t5 = -y / z * fy;
+    for (int c = 0; c < 3; c++) {
+        Ji[c] = -1. / z * (t0 * R[c] + t2 * R[6 + c]);
+        Ji[3 + c] = -1. / z * (t4 * R[3 + c] + t5 * R[6 + c]);
+    }
+    Jj[0] = x * y / z_2 * fx;
+    Jj[1] = -(1 + (x * x / z_2)) * fx;
+    Jj[2] = y / z * fx;
+    Jj[3] = -1. / z * fx;
+    Jj[4] = 0;
+    Jj[5] = x / z_2 * fx;
+    Jj[6] = (1 + y * y / z_2) * fy;
+    Jj[7] = -x * y / z_2 * fy;
+    Jj[8] = -x / z * fy;
+    Jj[9] = 0;
+    Jj[10] = -1. / z * fy;
+    Jj[11] = y / z_2 * fy;
+}
+
+struct BAShared {
+    double vp[BA_MAX_N]; /* PCG search direction p */
+    double vr[BA_MAX_N]; /* residual r             */
+    double red[BA_W];
+    double bc[8];
+};
+
+__device__ __forceinline__ double block_sum(double v, BAShared &s) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if (lane == 0) s.red[wave] = v;
+    __syncthreads();
+    double t = 0;
+    for (int w = 0; w < BA_W; w++) t += s.red[w];
+    return t;
+}
+__device__ __forceinline__ double block_max(double v, BAShared &s) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    __syncthreads();
+    if (lane == 0) s.red[wave] = v;
+    __syncthreads();
+    double t = s.red[0];
+    for (int w = 1; w < BA_W; w++) t = fmax(t, s.red[w]);
+    return t;
+}
+
+/* errors of all active edges at (poses, pts) -> err ; returns robust chi2 (activeRobustChi2) */
+__device__ double eval_chi2(const BAWin &w, double *D, const int32_t *I, const uint8_t *B, int64_t poses, int64_t pts,
+                            int64_t err, BAShared &s) {
+    double acc = 0;
+    for (int e = threadIdx.x; e < w.E; e += BA_T) {
+        const uint8_t f = B[w.flags + e];
+        if (!(f & 1)) continue;
+        double er[2], pc[3];
+        project_err(D + poses + (int64_t)I[w.cam + e] * 7, D + pts + (int64_t)I[w.pt + e] * 3, D + w.obs + (int64_t)e * 2, w.fx,
+                    w.fy, w.cx, w.cy, er, pc);
+        D[err + (int64_t)e * 2] = er[0];
+        D[err + (int64_t)e * 2 + 1] = er[1];
+        double c = (er[0] * er[0] + er[1] * er[1]) * D[w.info + e];
+        if (f & 2) c = huber_rho0(c, w.delta);
+        acc += c;
+    }
+    return block_sum(acc, s);
+}
+
+/* one LM iteration (OptimizationAlgorithmLevenberg::solve) for every window of the batch */
+__global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of_round, double pcg_tol2, int pcg_maxit,
+                                                       int debug) {
+    __shared__ BAShared s;
+    const BAWin w = bufs.wins[blockIdx.x];
+    double *D = bufs.D;
+    const int32_t *I = bufs.I;
+    const uint8_t *B = bufs.B;
+    double *st = D + w.st;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (st[ST_TERM] != 0.0) return; /* uniform: this window's round already terminated */
+    const int n = w.Ncf * 6;
+
+    /* ---- computeActiveErrors + activeRobustChi2 ---- */
+    double currentChi = eval_chi2(w, D, I, B, w.poses, w.pts, w.err, s);
+    if (tid == 0 && st[ST_HAVE_CHI0] == 0.0) {
+        st[ST_CHI0] = currentChi;
+        st[ST_HAVE_CHI0] = 1.0;
+    }
+    __syncthreads();
+
+    /* ---- buildSystem: Hll, bl, W (thread per point) ---- */
+    for (int p = tid; p < w.Np; p += BA_T) {
+        double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+        const int e0 = I[w.pt_start + p], e1 = I[w.pt_start + p + 1];
+        for (int e = e0; e < e1; e++) {
+            const uint8_t f = B[w.flags + e];
+            double *We = D + w.W + (int64_t)e * 18;
+            if (!(f & 1)) {
+                for (int i = 0; i < 18; i++) We[i] = 0.0;
+                continue;
+            }
+            const int c = I[w.cam + e];
+            const double *pose = D + w.poses + (int64_t)c * 7;
+            const double *X = D + w.pts + (int64_t)p * 3;
+            double R[9], pc[3];
+            quat_to_R(pose, R);
+            pc[0] = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + pose[4];
+            pc[1] = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + pose[5];
+            pc[2] = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + pose[6];
+            double Ji[6], Jj[12];
+            jacobians(pose, pc, w.fx, w.fy, Ji, Jj);
+            const double er0 = D[w.err + (int64_t)e * 2], er1 = D[w.err + (int64_t)e * 2 + 1];
+            const double info = D[w.info + e];
+            double wgt = info, r0 = -info * er0, r1 = -info * er1;
+            if (f & 2) {
+                const double rw = huber_w((er0 * er0 + er1 * er1) * info, w.delta);
+                wgt *= rw;
+                r0 *= rw;
+                r1 *= rw;
+            }
+            for (int a = 0; a < 3; a++) {
+                b[a] += Ji[a] * r0 + Ji[3 + a] * r1;
+                for (int bb = 0; bb < 3; bb++) H[a * 3 + bb] += wgt * (Ji[a] * Ji[bb] + Ji[3 + a] * Ji[3 + bb]);
+            }
+            const bool free_cam = I[w.slot + c] >= 0;
+            for (int a = 0; a < 6; a++)
+                for (int bb = 0; bb < 3; bb++)
+                    We[a * 3 + bb] = free_cam ? wgt * (Jj[a] * Ji[bb] + Jj[6 + a] * Ji[3 + bb]) : 0.0;
+        }
+        for (int i = 0; i < 9; i++) D[w.Hll + (int64_t)p * 9 + i] = H[i];
+        for (int i = 0; i < 3; i++) D[w.bl + (int64_t)p * 3 + i] = b[i];
+    }
+    /* ---- Hpp, bp: one wavefront per free camera, lanes over its edges, shuffle reduction ---- */
+    for (int c = wave; c < w.Nc; c += BA_W) {
+        const int sl = I[w.slot + c];
+        if (sl < 0) continue;
+        double acc[27];
+        for (int i = 0; i < 27; i++) acc[i] = 0.0;
+        const int k0 = I[w.cam_start + c], k1 = I[w.cam_start + c + 1];
+        const double *pose = D + w.poses + (int64_t)c * 7;
+        for (int k = k0 + lane; k < k1; k += 64) {
+            const int e = I[w.cam_edges + k];
+            const uint8_t f = B[w.flags + e];
+            if (!(f & 1)) continue;
+            const double *X = D + w.pts + (int64_t)I[w.pt + e] * 3;
+            double R[9], pc[3];
+            quat_to_R(pose, R);
+            pc[0] = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + pose[4];
+            pc[1] = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + pose[5];
+            pc[2] = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + pose[6];
+            double Ji[6], Jj[12];
+            jacobians(pose, pc, w.fx, w.fy, Ji, Jj);
+            const double er0 = D[w.err + (int64_t)e * 2], er1 = D[w.err + (int64_t)e * 2 + 1];
+            const double info = D[w.info + e];
+            double wgt = info, r0 = -info * er0, r1 = -info * er1;
+            if (f & 2) {
+                const double rw = huber_w((er0 * er0 + er1 * er1) * info, w.delta);
+                wgt *= rw;
+                r0 *= rw;
+                r1 *= rw;
+            }
+            int q = 0;
+            for (int a = 0; a < 6; a++)
+                for (int bb = a; bb < 6; bb++) acc[q++] += wgt * (Jj[a] * Jj[bb] + Jj[6 + a] * Jj[6 + bb]);
+            for (int a = 0; a < 6; a++) acc[21 + a] += Jj[a] * r0 + Jj[6 + a] * r1;
+        }
+        for (int i = 0; i < 27; i++) {
+            double v = acc[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            acc[i] = v;
+        }
+        if (lane == 0) {
+            int q = 0;
+            for (int a = 0; a < 6; a++)
+                for (int bb = a; bb < 6; bb++) {
+                    D[w.Hpp + (int64_t)sl * 36 + a * 6 + bb] = acc[q];
+                    D[w.Hpp + (int64_t)sl * 36 + bb * 6 + a] = acc[q];
+                    q++;
+                }
+            for (int a = 0; a < 6; a++) D[w.bp + (int64_t)sl * 6 + a] = acc[21 + a];
+        }
+    }
+    __syncthreads();
+
+    /* ---- computeLambdaInit on the first iteration of an optimize() call ---- */
+    double lambda = st[ST_LAMBDA], ni = st[ST_NI];
+    if (first_of_round) {
+        double m = 0;
+        for (int i = tid; i < w.Ncf * 6; i += BA_T) m = fmax(m, fabs(D[w.Hpp + (int64_t)(i / 6) * 36 + (i % 6) * 7]));
+        for (int i = tid; i < w.Np * 3; i += BA_T) m = fmax(m, fabs(D[w.Hll + (int64_t)(i / 3) * 9 + (i % 3) * 4]));
+        m = block_max(m, s);
+        lambda = 1e-5 * m;
+        ni = 2;
+    }
+
+    double rho = 0;
+    int qmax = 0;
+    int solves = 0, pcg_total = 0;
+    do {
+        /* ---- Dinv = (Hll + lambda I)^-1, Y = W Dinv (thread per point) ---- */
+        for (int p = tid; p < w.Np; p += BA_T) {
+            double Dm[9];
+            for (int i = 0; i < 9; i++) Dm[i] = D[w.Hll + (int64_t)p * 9 + i];
+            Dm[0] += lambda;
+            Dm[4] += lambda;
+            Dm[8] += lambda;
+            const double det = Dm[0] * (Dm[4] * Dm[8] - Dm[5] * Dm[7]) - Dm[1] * (Dm[3] * Dm[8] - Dm[5] * Dm[6]) +
+                               Dm[2] * (Dm[3] * Dm[7] - Dm[4] * Dm[6]);
+            const double id = 1.0 / det;
+            double Iv[9];
+            Iv[0] = (Dm[4] * Dm[8] - Dm[5] * Dm[7]) * id;
+            Iv[1] = (Dm[2] * Dm[7] - Dm[1] * Dm[8]) * id;
+            Iv[2] = (Dm[1] * Dm[5] - Dm[2] * Dm[4]) * id;
+            Iv[3] = (Dm[5] * Dm[6] - Dm[3] * Dm[8]) * id;
+            Iv[4] = (Dm[0] * Dm[8] - Dm[2] * Dm[6]) * id;
+            Iv[5] = (Dm[2] * Dm[3] - Dm[0] * Dm[5]) * id;
+            Iv[6] = (Dm[3] * Dm[7] - Dm[4] * Dm[6]) * id;
+            Iv[7] = (Dm[1] * Dm[6] - Dm[0] * Dm[7]) * id;
+            Iv[8] = (Dm[0] * Dm[4] - Dm[1] * Dm[3]) * id;
+            for (int i = 0; i < 9; i++) D[w.Dinv + (int64_t)p * 9 + i] = Iv[i];
+            const int e0 = I[w.pt_start + p], e1 = I[w.pt_start + p + 1];
+            for (int e = e0; e < e1; e++) {
+                const double *We = D + w.W + (int64_t)e * 18;
+                double *Ye = D + w.Y + (int64_t)e * 18;
+                for (int a = 0; a < 6; a++)
+                    for (int bb = 0; bb < 3; bb++)
+                        Ye[a * 3 + bb] = We[a * 3] * Iv[bb] + We[a * 3 + 1] * Iv[3 + bb] + We[a * 3 + 2] * Iv[6 + bb];
+            }
+        }
+        __syncthreads();
+        /* ---- S = Hpp + lambda I - sum Y W^T : one wavefront per non-zero block, lanes = 6x6 entries ---- */
+        for (int bk = wave; bk < w.nnzb; bk += BA_W) {
+            const int k0 = I[w.con_start + bk], k1 = I[w.con_start + bk + 1];
+            const int r = lane / 6, c = lane % 6;
+            double acc = 0;
+            if (lane < 36) {
+                for (int k = k0; k < k1; k++) {
+                    const double *Y1 = D + w.Y + (int64_t)I[w.con_e1 + k] * 18 + r * 3;
+                    const double *W2 = D + w.W + (int64_t)I[w.con_e2 + k] * 18 + c * 3;
+                    acc += Y1[0] * W2[0] + Y1[1] * W2[1] + Y1[2] * W2[2];
+                }
+                D[w.S + (int64_t)bk * 36 + lane] = -acc;
+            }
+        }
+        __syncthreads();
+        /* diagonal blocks: + Hpp + lambda I ; g = bp - sum_e Y_e bl  (thread per reduced row) */
+        for (int i = tid; i < n; i += BA_T) {
+            const int sl = i / 6, a = i % 6;
+            const int bd = I[w.blk_diag + sl];
+            double *Sd = D + w.S + (int64_t)bd * 36 + a * 6;
+            for (int c = 0; c < 6; c++) Sd[c] += D[w.Hpp + (int64_t)sl * 36 + a * 6 + c];
+            Sd[a] += lambda;
+            /* g */
+            const int cam = I[w.blk_row + w.Ncf + 1 + sl]; /* slot -> camera (stored behind the row starts) */
+            double gv = D[w.bp + (int64_t)sl * 6 + a];
+            const int k0 = I[w.cam_start + cam], k1 = I[w.cam_start + cam + 1];
+            for (int k = k0; k < k1; k++) {
+                const int e = I[w.cam_edges + k];
+                const double *Ye = D + w.Y + (int64_t)e * 18 + a * 3;
+                const double *blp = D + w.bl + (int64_t)I[w.pt + e] * 3;
+                gv -= Ye[0] * blp[0] + Ye[1] * blp[1] + Ye[2] * blp[2];
+            }
+            D[w.g + i] = gv;
+        }
+        __syncthreads();
+        /* ---- block-Jacobi preconditioner: inverse of the 6x6 diagonal blocks (thread per camera) ---- */
+        bool ok_local = true;
+        for (int sl = tid; sl < w.Ncf; sl += BA_T) {
+            double A[36], Linv[36];
+            const double *Sd = D + w.S + (int64_t)I[w.blk_diag + sl] * 36;
+            for (int i = 0; i < 36; i++) A[i] = Sd[i];
+            /* Cholesky A = L L^T */
+            for (int j = 0; j < 6; j++) {
+                double d = A[j * 6 + j];
+                for (int k = 0; k < j; k++) d -= A[j * 6 + k] * A[j * 6 + k];
+                if (!(d > 0)) {
+                    ok_local = false;
+                    d = 1.0;
+                }
+                d = sqrt(d);
+                A[j * 6 + j] = d;
+                for (int i = j + 1; i < 6; i++) {
+                    double v = A[i * 6 + j];
+                    for (int k = 0; k < j; k++) v -= A[i * 6 + k] * A[j * 6 + k];
+                    A[i * 6 + j] = v / d;
+                }
+            }
+            /* Linv */
+            for (int i = 0; i < 36; i++) Linv[i] = 0;
+            for (int j = 0; j < 6; j++) {
+                Linv[j * 6 + j] = 1.0 / A[j * 6 + j];
+                for (int i = j + 1; i < 6; i++) {
+                    double v = 0;
+                    for (int k = j; k < i; k++) v -= A[i * 6 + k] * Linv[k * 6 + j];
+                    Linv[i * 6 + j] = v / A[i * 6 + i];
+                }
+            }
+            double *Mi = D + w.Minv + (int64_t)sl * 36;
+            for (int i = 0; i < 6; i++)
+                for (int j = 0; j < 6; j++) {
+                    double v = 0;
+                    for (int k = (i > j ? i : j); k < 6; k++) v += Linv[k * 6 + i] * Linv[k * 6 + j];
+                    Mi[i * 6 + j] = v;
+                }
+        }
+        /* ---- PCG on S x = g ---- */
+        double xi[3] = {0, 0, 0}, ri[3], zi[3], pi[3]; /* each thread owns rows tid, tid+BA_T, tid+2*BA_T */
+        double rz_loc = 0, gg_loc = 0;
+        __syncthreads();
+        for (int q = 0; q < 3; q++) {
+            const int i = tid + q * BA_T;
+            ri[q] = (i < n) ? D[w.g + i] : 0.0;
+            if (i < n) s.vr[i] = ri[q];
+        }
+        __syncthreads();
+        for (int q = 0; q < 3; q++) {
+            const int i = tid + q * BA_T;
+            zi[q] = 0;
+            if (i < n) {
+                const int sl = i / 6, a = i % 6;
+                const double *Mi = D + w.Minv + (int64_t)sl * 36 + a * 6;
+                double v = 0;
+                for (int c = 0; c < 6; c++) v += Mi[c] * s.vr[sl * 6 + c];
+                zi[q] = v;
+                s.vp[i] = v;
+            }
+            pi[q] = zi[q];
+            rz_loc += ri[q] * zi[q];
+            gg_loc += ri[q] * ri[q];
+        }
+        double rz = block_sum(rz_loc, s);
+        const double rz0 = rz;
+        bool ok2 = (block_sum(ok_local ? 0.0 : 1.0, s) == 0.0);
+        int it = 0;
+        if (n > 0 && ok2 && rz0 > 0) {
+            for (it = 0; it < pcg_maxit; it++) {
+                /* Ap = S p : block-CSR row product, p read from LDS */
+                double Ap[3], pAp_loc = 0;
+                for (int q = 0; q < 3; q++) {
+                    const int i = tid + q * BA_T;
+                    Ap[q] = 0;
+                    if (i < n) {
+                        const int sl = i / 6, a = i % 6;
+                        const int b0 = I[w.blk_row + sl], b1 = I[w.blk_row + sl + 1];
+                        double v = 0;
+                        for (int bk = b0; bk < b1; bk++) {
+                            const double *Sr = D + w.S + (int64_t)bk * 36 + a * 6;
+                            const double *pv = s.vp + I[w.blk_col + bk] * 6;
+                            v += Sr[0] * pv[0] + Sr[1] * pv[1] + Sr[2] * pv[2] + Sr[3] * pv[3] + Sr[4] * pv[4] + Sr[5] * pv[5];
+                        }
+                        Ap[q] = v;
+                        pAp_loc += pi[q] * v;
+                    }
+                }
+                const double pAp = block_sum(pAp_loc, s);
+                if (!(pAp > 0)) { /* not positive definite: same outcome as a failed Cholesky */
+                    ok2 = false;
+                    break;
+                }
+                const double alpha = rz / pAp;
+                for (int q = 0; q < 3; q++) {
+                    const int i = tid + q * BA_T;
+                    xi[q] += alpha * pi[q];
+                    ri[q] -= alpha * Ap[q];
+                    if (i < n) s.vr[i] = ri[q];
+                }
+                __syncthreads();
+                double rz_new_loc = 0;
+                for (int q = 0; q < 3; q++) {
+                    const int i = tid + q * BA_T;
+                    if (i < n) {
+                        const int sl = i / 6, a = i % 6;
+                        const double *Mi = D + w.Minv + (int64_t)sl * 36 + a * 6;
+                        double v = 0;
+                        for (int c = 0; c < 6; c++) v += Mi[c] * s.vr[sl * 6 + c];
+                        zi[q] = v;
+                        rz_new_loc += ri[q] * v;
+                    }
+                }
+                const double rz_new = block_sum(rz_new_loc, s);
+                if (rz_new <= pcg_tol2 * rz0) {
+                    it++;
+                    break;
+                }
+                const double beta = rz_new / rz;
+                rz = rz_new;
+                for (int q = 0; q < 3; q++) {
+                    const int i = tid + q * BA_T;
+                    pi[q] = zi[q] + beta * pi[q];
+                    if (i < n) s.vp[i] = pi[q];
+                }
+                __syncthreads();
+            }
+        }
+        pcg_total += it;
+        solves++;
+        for (int q = 0; q < 3; q++) {
+            const int i = tid + q * BA_T;
+            if (i < n) D[w.x + i] = ok2 ? xi[q] : 0.0;
+        }
+        __syncthreads();
+        /* ---- back-substitution: xl = Dinv (bl - sum_e W_e^T x_c) (thread per point) + trial update ---- */
+        double scale_loc = 0;
+        for (int p = tid; p < w.Np; p += BA_T) {
+            double cl[3] = {D[w.bl + (int64_t)p * 3], D[w.bl + (int64_t)p * 3 + 1], D[w.bl + (int64_t)p * 3 + 2]};
+            const int e0 = I[w.pt_start + p], e1 = I[w.pt_start + p + 1];
+            for (int e = e0; e < e1; e++) {
+                const int sl = I[w.slot + I[w.cam + e]];
+                if (sl < 0) continue;
+                const double *We = D + w.W + (int64_t)e * 18;
+                const double *xc = D + w.x + sl * 6;
+                for (int bb = 0; bb < 3; bb++)
+                    for (int a = 0; a < 6; a++) cl[bb] -= We[a * 3 + bb] * xc[a];
+            }
+            const double *Iv = D + w.Dinv + (int64_t)p * 9;
+            for (int a = 0; a < 3; a++) {
+                const double v = ok2 ? (Iv[a * 3] * cl[0] + Iv[a * 3 + 1] * cl[1] + Iv[a * 3 + 2] * cl[2]) : 0.0;
+                D[w.pts_t + (int64_t)p * 3 + a] = D[w.pts + (int64_t)p * 3 + a] + v;
+                scale_loc += v * (lambda * v + D[w.bl + (int64_t)p * 3 + a]);
+            }
+        }
+        for (int c = tid; c < w.Nc; c += BA_T) {
+            const int sl = I[w.slot + c];
+            if (sl >= 0 && ok2) {
+                double u[6];
+                for (int a = 0; a < 6; a++) {
+                    u[a] = D[w.x + sl * 6 + a];
+                    scale_loc += u[a] * (lambda * u[a] + D[w.bp + (int64_t)sl * 6 + a]);
+                }
+                se3_exp_mul(u, D + w.poses + (int64_t)c * 7, D + w.poses_t + (int64_t)c * 7);
+            } else {
+                for (int a = 0; a < 7; a++) D[w.poses_t + (int64_t)c * 7 + a] = D[w.poses + (int64_t)c * 7 + a];
+            }
+        }
+        __syncthreads();
+        double tempChi = eval_chi2(w, D, I, B, w.poses_t, w.pts_t, w.err_t, s);
+        if (!ok2) tempChi = 1.7976931348623157e308;
+        double scale = block_sum(scale_loc, s);
+        if (!ok2) scale = 0;
+        scale += 1e-3;
+        rho = (currentChi - tempChi) / scale;
+        if (rho > 0 && isfinite(tempChi)) { /* accept: keep the trial state */
+            double alpha = 1. - pow((2 * rho - 1), 3);
+            alpha = fmin(alpha, 2. / 3.);
+            lambda *= fmax(1. / 3., alpha);
+            ni = 2;
+            currentChi = tempChi;
+            for (int i = tid; i < w.Nc * 7; i += BA_T) D[w.poses + i] = D[w.poses_t + i];
+            for (int i = tid; i < w.Np * 3; i += BA_T) D[w.pts + i] = D[w.pts_t + i];
+            for (int i = tid; i < w.E * 2; i += BA_T) D[w.err + i] = D[w.err_t + i];
+        } else {
+            lambda *= ni;
+            ni *= 2;
+        }
+        qmax++;
+        if (debug && tid == 0)
+            printf("[dev] win %d trial %d ok %d pcg %d cur %.10e temp %.10e rho %.6e lambda %.6e\n", (int)blockIdx.x, qmax,
+                   (int)ok2, it, currentChi, tempChi, rho, lambda);
+        __syncthreads();
+    } while (rho < 0 && qmax < 10);
+
+    if (tid == 0) {
+        st[ST_LAMBDA] = lambda;
+        st[ST_NI] = ni;
+        st[ST_CHI] = currentChi;
+        st[ST_ITERS] += 1;
+        st[ST_SOLVES] += solves;
+        st[ST_PCG_ITERS] += pcg_total;
+        if (qmax == 10 || rho == 0) st[ST_TERM] = 1.0; /* OptimizationAlgorithmLevenberg returns Terminate */
+    }
+}
+
+/* between rounds: re-evaluate every edge at the accepted estimate, switch off edges with chi2 above
+ * the threshold or non-positive depth, optionally drop the robust kernel (LocalBundleAdjustment) */
+__global__ __launch_bounds__(BA_T) void k_ba_classify(BABufs bufs, int drop_robust, int final_only) {
+    __shared__ BAShared s;
+    const BAWin w = bufs.wins[blockIdx.x];
+    double *D = bufs.D;
+    const int32_t *I = bufs.I;
+    uint8_t *B = bufs.B;
+    double acc = 0;
+    for (int e = threadIdx.x; e < w.E; e += BA_T) {
+        uint8_t f = B[w.flags + e];
+        double er[2], pc[3];
+        project_err(D + w.poses + (int64_t)I[w.cam + e] * 7, D + w.pts + (int64_t)I[w.pt + e] * 3, D + w.obs + (int64_t)e * 2, w.fx,
+                    w.fy, w.cx, w.cy, er, pc);
+        D[w.err + (int64_t)e * 2] = er[0];
+        D[w.err + (int64_t)e * 2 + 1] = er[1];
+        const double c = (er[0] * er[0] + er[1] * er[1]) * D[w.info + e];
+        if (!final_only) {
+            if (c > w.chi2_thr || !(pc[2] > 0.0)) f &= ~1;
+            if (drop_robust) f &= ~2;
+            B[w.flags + e] = f;
+        }
+        if (f & 1) acc += (f & 2) ? huber_rho0(c, w.delta) : c;
+    }
+    acc = block_sum(acc, s);
+    if (threadIdx.x == 0) {
+        D[w.st + ST_CHI] = acc;
+        if (!final_only) D[w.st + ST_TERM] = 0.0; /* a new optimize() call starts */
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+struct BASolver {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int max_cams, max_points, max_obs, max_batch;
+    double *dD = nullptr;
+    int32_t *dI = nullptr;
+    uint8_t *dB = nullptr;
+    BAWin *dW = nullptr;
+    size_t capD = 0, capI = 0, capB = 0, capW = 0;
+    double pcg_tol2 = 1e-26; /* relative M^-1-norm of the residual, squared */
+};
+
+extern "C" int ba_create(int max_cams, int max_points, int max_obs, int max_batch, int device_id, BASolver **out) {
+    if (!out || max_cams <= 0 || max_points <= 0 || max_obs <= 0 || max_batch <= 0) return ORB_E_INVALID;
+    if (max_cams * 6 > BA_MAX_N) {
+        b_err = "ba_create: more than 256 free cameras per window are not supported";
+        return ORB_E_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return ORB_E_NO_DEVICE;
+    BCHK(hipSetDevice(device_id));
+    BASolver *s = new BASolver();
+    s->device = device_id;
+    s->max_cams = max_cams;
+    s->max_points = max_points;
+    s->max_obs = max_obs;
+    s->max_batch = max_batch;
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete s;
+        return ORB_E_HIP;
+    }
+    const char *tol = getenv("ORBSLAM_AMD_PCG_TOL");
+    if (tol) s->pcg_tol2 = atof(tol) * atof(tol);
+    *out = s;
+    return ORB_OK;
+}
+
+extern "C" void ba_destroy(BASolver *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    (void)hipFree(s->dD);
+    (void)hipFree(s->dI);
+    (void)hipFree(s->dB);
+    (void)hipFree(s->dW);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+template <typename T> static int ba_grow(T *&p, size_t &cap, size_t need) {
+    if (need <= cap && p) return ORB_OK;
+    if (p) BCHK(hipFree(p));
+    p = nullptr;
+    cap = 0;
+    BCHK(hipMalloc((void **)&p, std::max<size_t>(need * sizeof(T), 256)));
+    cap = need;
+    return ORB_OK;
+}
+
+struct HostWin {
+    BAWin w;
+    std::vector<int> perm; /* sorted edge -> caller's edge index */
+};
+/* fields of BAWin that are device-only scratch: their offsets are relative to the scratch base until
+ * ba_solve_batch adds the size of the staged (uploaded) region */
+static int64_t BAWin::*const kScratchFields[] = {&BAWin::poses_t, &BAWin::pts_t, &BAWin::err, &BAWin::err_t, &BAWin::W,
+                                                 &BAWin::Y,       &BAWin::Hpp,   &BAWin::bp,  &BAWin::Hll,   &BAWin::bl,
+                                                 &BAWin::Dinv,    &BAWin::S,     &BAWin::g,   &BAWin::Minv,  &BAWin::x,
+                                                 &BAWin::xl};
+
+/* lay one problem out in the host staging vectors; returns error code */
+static int stage_problem(const BAProblem *p, std::vector<double> &hD, size_t &scratchD, std::vector<int32_t> &hI,
+                         std::vector<uint8_t> &hB, HostWin &hw) {
+    if (!p || p->n_cams <= 0 || p->n_points < 0 || p->n_obs < 0 || !p->poses || !p->fixed ||
+        (p->n_points && !p->points) || (p->n_obs && (!p->obs || !p->cam_idx || !p->pt_idx || !p->inv_sigma2)) ||
+        p->n_rounds < 1 || p->n_rounds > 4)
+        return ORB_E_INVALID;
+    const int Nc = p->n_cams, Np = p->n_points, E = p->n_obs;
+    BAWin &w = hw.w;
+    memset(&w, 0, sizeof(w));
+    w.Nc = Nc;
+    w.Np = Np;
+    w.E = E;
+    w.fx = p->fx; w.fy = p->fy; w.cx = p->cx; w.cy = p->cy;
+    w.delta = p->huber_delta;
+    w.chi2_thr = p->chi2_threshold;
+    /* edges sorted by point (stable) */
+    std::vector<int> cnt(Np + 1, 0);
+    for (int e = 0; e < E; e++) {
+        if (p->pt_idx[e] < 0 || p->pt_idx[e] >= Np || p->cam_idx[e] < 0 || p->cam_idx[e] >= Nc) return ORB_E_INVALID;
+        cnt[p->pt_idx[e] + 1]++;
+    }
+    for (int i = 0; i < Np; i++) cnt[i + 1] += cnt[i];
+    std::vector<int> pos(cnt.begin(), cnt.end() - 1);
+    hw.perm.assign(E, 0);
+    for (int e = 0; e < E; e++) hw.perm[pos[p->pt_idx[e]]++] = e;
+    /* free camera slots */
+    std::vector<int> slot(Nc, -1), slot2cam;
+    for (int c = 0; c < Nc; c++)
+        if (!p->fixed[c]) {
+            slot[c] = (int)slot2cam.size();
+            slot2cam.push_back(c);
+        }
+    const int Ncf = (int)slot2cam.size();
+    w.Ncf = Ncf;
+    if (Ncf * 6 > BA_MAX_N) return ORB_E_CAPACITY;
+    /* camera edge lists (sorted-edge indices) */
+    std::vector<int> cstart(Nc + 1, 0), cedges(E);
+    for (int k = 0; k < E; k++) cstart[p->cam_idx[hw.perm[k]] + 1]++;
+    for (int c = 0; c < Nc; c++) cstart[c + 1] += cstart[c];
+    {
+        std::vector<int> cp(cstart.begin(), cstart.end() - 1);
+        for (int k = 0; k < E; k++) cedges[cp[p->cam_idx[hw.perm[k]]]++] = k;
+    }
+    /* reduced-system block structure + contribution lists */
+    std::vector<std::vector<int>> rowcols(Ncf);
+    for (int sl = 0; sl < Ncf; sl++) rowcols[sl].push_back(sl); /* diagonal always present */
+    for (int pt = 0; pt < Np; pt++)
+        for (int a = cnt[pt]; a < cnt[pt + 1]; a++) {
+            const int s1 = slot[p->cam_idx[hw.perm[a]]];
+            if (s1 < 0) continue;
+            for (int b = cnt[pt]; b < cnt[pt + 1]; b++) {
+                const int s2 = slot[p->cam_idx[hw.perm[b]]];
+                if (s2 >= 0) rowcols[s1].push_back(s2);
+            }
+        }
+    std::vector<int> brow(Ncf + 1, 0), bcol, bdiag(Ncf, 0);
+    for (int sl = 0; sl < Ncf; sl++) {
+        auto &v = rowcols[sl];
+        std::sort(v.begin(), v.end());
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+        brow[sl + 1] = brow[sl] + (int)v.size();
+        for (int c : v) {
+            if (c == sl) bdiag[sl] = (int)bcol.size();
+            bcol.push_back(c);
+        }
+    }
+    const int nnzb = (int)bcol.size();
+    w.nnzb = nnzb;
+    auto block_of = [&](int s1, int s2) {
+        const auto &v = rowcols[s1];
+        return brow[s1] + (int)(std::lower_bound(v.begin(), v.end(), s2) - v.begin());
+    };
+    std::vector<int> ccount(nnzb + 1, 0);
+    for (int pt = 0; pt < Np; pt++)
+        for (int a = cnt[pt]; a < cnt[pt + 1]; a++) {
+            const int s1 = slot[p->cam_idx[hw.perm[a]]];
+            if (s1 < 0) continue;
+            for (int b = cnt[pt]; b < cnt[pt + 1]; b++) {
+                const int s2 = slot[p->cam_idx[hw.perm[b]]];
+                if (s2 >= 0) ccount[block_of(s1, s2) + 1]++;
+            }
+        }
+    for (int i = 0; i < nnzb; i++) ccount[i + 1] += ccount[i];
+    const int ncon = ccount[nnzb];
+    std::vector<int> ce1(ncon), ce2(ncon);
+    {
+        std::vector<int> cp(ccount.begin(), ccount.end() - 1);
+        for (int pt = 0; pt < Np; pt++)
+            for (int a = cnt[pt]; a < cnt[pt + 1]; a++) {
+                const int s1 = slot[p->cam_idx[hw.perm[a]]];
+                if (s1 < 0) continue;
+                for (int b = cnt[pt]; b < cnt[pt + 1]; b++) {
+                    const int s2 = slot[p->cam_idx[hw.perm[b]]];
+                    if (s2 < 0) continue;
+                    const int k = cp[block_of(s1, s2)]++;
+                    ce1[k] = a;
+                    ce2[k] = b;
+                }
+            }
+    }
+    /* ---- lay out ---- */
+    auto allocD = [&](size_t n) {
+        size_t o = hD.size();
+        hD.resize(o + ((n + 1) & ~(size_t)1), 0.0);
+        return (int64_t)o;
+    };
+    auto allocS = [&](size_t n) { /* device-only scratch */
+        size_t o = scratchD;
+        scratchD += (n + 1) & ~(size_t)1;
+        return (int64_t)o;
+    };
+    auto allocI = [&](size_t n) {
+        size_t o = hI.size();
+        hI.resize(o + n, 0);
+        return (int64_t)o;
+    };
+    w.poses = allocD((size_t)Nc * 7);
+    w.poses_t = allocS((size_t)Nc * 7);
+    w.pts = allocD((size_t)Np * 3);
+    w.pts_t = allocS((size_t)Np * 3);
+    w.obs = allocD((size_t)E * 2);
+    w.info = allocD(E);
+    w.err = allocS((size_t)E * 2);
+    w.err_t = allocS((size_t)E * 2);
+    w.W = allocS((size_t)E * 18);
+    w.Y = allocS((size_t)E * 18);
+    w.Hpp = allocS((size_t)Ncf * 36);
+    w.bp = allocS((size_t)Ncf * 6);
+    w.Hll = allocS((size_t)Np * 9);
+    w.bl = allocS((size_t)Np * 3);
+    w.Dinv = allocS((size_t)Np * 9);
+    w.S = allocS((size_t)nnzb * 36);
+    w.g = allocS((size_t)Ncf * 6);
+    w.Minv = allocS((size_t)Ncf * 36);
+    w.x = allocS((size_t)Ncf * 6);
+    w.xl = allocS(2);
+    w.st = allocD(ST_COUNT);
+    for (int c = 0; c < Nc; c++) {
+        double q[4] = {p->poses[c * 7], p->poses[c * 7 + 1], p->poses[c * 7 + 2], p->poses[c * 7 + 3]};
+        if (q[0] < 0) { /* SE3Quat ctor: normalizeRotation */
+            q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3];
+        }
+        const double nrm = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        for (int i = 0; i < 4; i++) hD[w.poses + c * 7 + i] = q[i] / nrm;
+        for (int i = 0; i < 3; i++) hD[w.poses + c * 7 + 4 + i] = p->poses[c * 7 + 4 + i];
+    }
+    for (int i = 0; i < Np * 3; i++) hD[w.pts + i] = p->points[i];
+    for (int k = 0; k < E; k++) {
+        const int e = hw.perm[k];
+        hD[w.obs + 2 * k] = p->obs[2 * e];
+        hD[w.obs + 2 * k + 1] = p->obs[2 * e + 1];
+        hD[w.info + k] = p->inv_sigma2[e];
+    }
+    w.cam = allocI(E);
+    w.pt = allocI(E);
+    for (int k = 0; k < E; k++) {
+        hI[w.cam + k] = p->cam_idx[hw.perm[k]];
+        hI[w.pt + k] = p->pt_idx[hw.perm[k]];
+    }
+    w.pt_start = allocI(Np + 1);
+    for (int i = 0; i <= Np; i++) hI[w.pt_start + i] = cnt[i];
+    w.cam_start = allocI(Nc + 1);
+    for (int i = 0; i <= Nc; i++) hI[w.cam_start + i] = cstart[i];
+    w.cam_edges = allocI(E);
+    for (int i = 0; i < E; i++) hI[w.cam_edges + i] = cedges[i];
+    w.slot = allocI(Nc);
+    for (int i = 0; i < Nc; i++) hI[w.slot + i] = slot[i];
+    w.blk_row = allocI((size_t)Ncf + 1 + Ncf); /* row starts, then slot -> camera */
+    for (int i = 0; i <= Ncf; i++) hI[w.blk_row + i] = brow[i];
+    for (int i = 0; i < Ncf; i++) hI[w.blk_row + Ncf + 1 + i] = slot2cam[i];
+    w.blk_col = allocI(nnzb);
+    for (int i = 0; i < nnzb; i++) hI[w.blk_col + i] = bcol[i];
+    w.blk_diag = allocI(Ncf);
+    for (int i = 0; i < Ncf; i++) hI[w.blk_diag + i] = bdiag[i];
+    w.con_start = allocI((size_t)nnzb + 1);
+    for (int i = 0; i <= nnzb; i++) hI[w.con_start + i] = ccount[i];
+    w.con_e1 = allocI(ncon);
+    w.con_e2 = allocI(ncon);
+    for (int i = 0; i < ncon; i++) {
+        hI[w.con_e1 + i] = ce1[i];
+        hI[w.con_e2 + i] = ce2[i];
+    }
+    w.flags = (int64_t)hB.size();
+    hB.resize(hB.size() + ((E + 15) & ~15), 0);
+    for (int k = 0; k < E; k++) hB[w.flags + k] = (uint8_t)(1 | (p->huber_delta > 0 ? 2 : 0));
+    return ORB_OK;
+}
+
+extern "C" int ba_solve_batch(BASolver *s, const BAProblem *probs, BAResult *res, int nwin) {
+    if (!s || !probs || !res || nwin <= 0) return ORB_E_INVALID;
+    if (nwin > s->max_batch) return ORB_E_CAPACITY;
+    BCHK(hipSetDevice(s->device));
+    const BAProblem &P0 = probs[0];
+    for (int i = 0; i < nwin; i++) {
+        if (probs[i].stop && *probs[i].stop) return ORB_E_STOPPED;
+        if (probs[i].n_rounds != P0.n_rounds || memcmp(probs[i].rounds, P0.rounds, sizeof(P0.rounds)) ||
+            probs[i].drop_robust_after != P0.drop_robust_after) {
+            b_err = "ba_solve_batch: all windows of a batch must share one iteration schedule";
+            return ORB_E_INVALID;
+        }
+        if (!res[i].poses || (probs[i].n_points && !res[i].points)) return ORB_E_INVALID;
+    }
+    std::vector<double> hD;
+    std::vector<int32_t> hI;
+    std::vector<uint8_t> hB;
+    std::vector<HostWin> hw(nwin);
+    std::vector<BAWin> wins(nwin);
+    size_t scratchD = 0;
+    for (int i = 0; i < nwin; i++) {
+        int rc = stage_problem(&probs[i], hD, scratchD, hI, hB, hw[i]);
+        if (rc) return rc;
+    }
+    for (int i = 0; i < nwin; i++) {
+        for (auto f : kScratchFields) hw[i].w.*f += (int64_t)hD.size();
+        wins[i] = hw[i].w;
+    }
+    int rc;
+    if ((rc = ba_grow(s->dD, s->capD, hD.size() + scratchD))) return rc;
+    if ((rc = ba_grow(s->dI, s->capI, std::max<size_t>(hI.size(), 1)))) return rc;
+    if ((rc = ba_grow(s->dB, s->capB, std::max<size_t>(hB.size(), 1)))) return rc;
+    if ((rc = ba_grow(s->dW, s->capW, (size_t)nwin))) return rc;
+    BCHK(hipMemcpyAsync(s->dD, hD.data(), hD.size() * 8, hipMemcpyHostToDevice, s->stream));
+    if (!hI.empty()) BCHK(hipMemcpyAsync(s->dI, hI.data(), hI.size() * 4, hipMemcpyHostToDevice, s->stream));
+    if (!hB.empty()) BCHK(hipMemcpyAsync(s->dB, hB.data(), hB.size(), hipMemcpyHostToDevice, s->stream));
+    BCHK(hipMemcpyAsync(s->dW, wins.data(), (size_t)nwin * sizeof(BAWin), hipMemcpyHostToDevice, s->stream));
+    BABufs bufs{s->dD, s->dI, s->dB, s->dW};
+    auto stopped = [&]() {
+        for (int i = 0; i < nwin; i++)
+            if (probs[i].stop && *probs[i].stop) return true;
+        return false;
+    };
+    int maxn = 0;
+    for (int i = 0; i < nwin; i++) maxn = std::max(maxn, wins[i].Ncf * 6);
+    const int pcg_maxit = 6 * maxn + 100; /* CG needs > n steps in floating point when S is ill-conditioned */
+    bool halted = false;
+    for (int round = 0; round < P0.n_rounds && !halted; round++) {
+        for (int it = 0; it < P0.rounds[round]; it++) {
+            if (stopped()) { /* g2o polls the force-stop flag between iterations */
+                halted = true;
+                break;
+            }
+            hipLaunchKernelGGL(k_ba_iteration, dim3(nwin), dim3(BA_T), 0, s->stream, bufs, it == 0 ? 1 : 0, s->pcg_tol2,
+                               pcg_maxit, getenv("ORBSLAM_AMD_BA_DEBUG") ? 1 : 0);
+            BCHK(hipGetLastError());
+            /* the stop flag must be observed between iterations, as the reference's optimizer would */
+            bool any_stop_ptr = false;
+            for (int i = 0; i < nwin; i++) any_stop_ptr |= probs[i].stop != nullptr;
+            if (any_stop_ptr) BCHK(hipStreamSynchronize(s->stream));
+        }
+        if (halted) break;
+        if (round + 1 < P0.n_rounds) {
+            if (stopped()) break; /* bDoMore == false */
+            hipLaunchKernelGGL(k_ba_classify, dim3(nwin), dim3(BA_T), 0, s->stream, bufs,
+                               P0.drop_robust_after == round ? 1 : 0, 0);
+            BCHK(hipGetLastError());
+        }
+    }
+    hipLaunchKernelGGL(k_ba_classify, dim3(nwin), dim3(BA_T), 0, s->stream, bufs, 0, 1);
+    BCHK(hipGetLastError());
+    /* results */
+    for (int i = 0; i < nwin; i++) { /* only poses, points and the LM state come back */
+        const BAWin &w = wins[i];
+        BCHK(hipMemcpyAsync(&hD[w.poses], s->dD + w.poses, (size_t)w.Nc * 7 * 8, hipMemcpyDeviceToHost, s->stream));
+        if (w.Np) BCHK(hipMemcpyAsync(&hD[w.pts], s->dD + w.pts, (size_t)w.Np * 3 * 8, hipMemcpyDeviceToHost, s->stream));
+        BCHK(hipMemcpyAsync(&hD[w.st], s->dD + w.st, (size_t)ST_COUNT * 8, hipMemcpyDeviceToHost, s->stream));
+    }
+    if (!hB.empty()) BCHK(hipMemcpyAsync(hB.data(), s->dB, hB.size(), hipMemcpyDeviceToHost, s->stream));
+    BCHK(hipStreamSynchronize(s->stream));
+    for (int i = 0; i < nwin; i++) {
+        const BAWin &w = wins[i];
+        memcpy(res[i].poses, &hD[w.poses], (size_t)w.Nc * 7 * 8);
+        if (w.Np) memcpy(res[i].points, &hD[w.pts], (size_t)w.Np * 3 * 8);
+        if (res[i].outlier)
+            for (int k = 0; k < w.E; k++) res[i].outlier[hw[i].perm[k]] = (hB[w.flags + k] & 1) ? 0 : 1;
+        res[i].chi2_initial = hD[w.st + ST_CHI0];
+        res[i].chi2_final = hD[w.st + ST_CHI];
+        res[i].iterations = (int)hD[w.st + ST_ITERS];
+        res[i].lin_solves = (int)hD[w.st + ST_SOLVES];
+    }
+    return ORB_OK;
+}
+
+extern "C" int ba_solve(BASolver *s, const BAProblem *p, BAResult *r) { return ba_solve_batch(s, p, r, 1); }
+
+/* ================================================================================================
+ * Optimizer::PoseOptimization (reference src/Optimizer.cpp:131-261): one free SE3 vertex, n unary
+ * EdgeSE3ProjectXYZOnlyPose edges with fixed Xw, Huber delta = 5.99 [sic] (:169), 4 x optimize(10)
+ * with chi2 > 5.991 relabelling (:213-247), robust kernel removed after the round with it == 2.
+ * The whole schedule runs in ONE launch of ONE 256-thread workgroup: lanes stride over the edges,
+ * the 6x6 system is reduced across the workgroup and solved by thread 0.
+ * ================================================================================================ */
+#define PO_T 256
+struct POShared {
+    double red[PO_T / 64][28];
+    double pose[7], trial[7];
+    double bc[4];
+};
+
+__device__ __forceinline__ void po_reduce(double *v, int nv, POShared &s, double *out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = 0; i < nv; i++) {
+        double t = v[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+        v[i] = t;
+    }
+    __syncthreads();
+    if (lane == 0)
+        for (int i = 0; i < nv; i++) s.red[wave][i] = v[i];
+    __syncthreads();
+    for (int i = 0; i < nv; i++) {
+        double t = 0;
+        for (int w = 0; w < PO_T / 64; w++) t += s.red[w][i];
+        out[i] = t;
+    }
+}
+
+__device__ double po_chi2(const double *pose, const double *xw, const double *obs, const double *info, const uint8_t *fl,
+                          int n, double fx, double fy, double cx, double cy, double delta, POShared &s) {
+    double acc = 0;
+    for (int i = threadIdx.x; i < n; i += PO_T) {
+        if (!(fl[i] & 1)) continue;
+        double e[2], pc[3];
+        project_err(pose, xw + (int64_t)i * 3, obs + (int64_t)i * 2, fx, fy, cx, cy, e, pc);
+        double c = (e[0] * e[0] + e[1] * e[1]) * info[i];
+        if (fl[i] & 2) c = huber_rho0(c, delta);
+        acc += c;
+    }
+    double out;
+    po_reduce(&acc, 1, s, &out);
+    return out;
+}
+
+__global__ __launch_bounds__(PO_T) void k_pose_opt(double *pose7, const double *xw, const double *obs, const double *info,
+                                                    uint8_t *fl, uint8_t *outlier, int n, double fx, double fy, double cx,
+                                                    double cy, int32_t *n_inliers) {
+    __shared__ POShared s;
+    const int tid = threadIdx.x;
+    const double delta = 5.99;
+    if (tid < 7) s.pose[tid] = pose7[tid];
+    for (int i = tid; i < n; i += PO_T) {
+        fl[i] = 3; /* active + robust */
+        outlier[i] = 0;
+    }
+    __syncthreads();
+    if (tid == 0) quat_normalize(s.pose);
+    __syncthreads();
+    int nBads = 0;
+    double lambda = 0, ni = 2;
+    for (int it = 0; it < 4; it++) {
+        bool ok = true;
+        for (int k = 0; k < 10 && ok; k++) {
+            double currentChi = po_chi2(s.pose, xw, obs, info, fl, n, fx, fy, cx, cy, delta, s);
+            double acc[28];
+            for (int i = 0; i < 28; i++) acc[i] = 0;
+            for (int i = tid; i < n; i += PO_T) {
+                if (!(fl[i] & 1)) continue;
+                double e[2], pc[3], Ji[6], Jj[12];
+                project_err(s.pose, xw + (int64_t)i * 3, obs + (int64_t)i * 2, fx, fy, cx, cy, e, pc);
+                jacobians(s.pose, pc, fx, fy, Ji, Jj);
+                double wgt = info[i], r0 = -wgt * e[0], r1 = -wgt * e[1];
+                if (fl[i] & 2) {
+                    const double rw = huber_w((e[0] * e[0] + e[1] * e[1]) * info[i], delta);
+                    wgt *= rw;
+                    r0 *= rw;
+                    r1 *= rw;
+                }
+                int q = 0;
+                for (int a = 0; a < 6; a++)
+                    for (int b = a; b < 6; b++) acc[q++] += wgt * (Jj[a] * Jj[b] + Jj[6 + a] * Jj[6 + b]);
+                for (int a = 0; a < 6; a++) acc[21 + a] += Jj[a] * r0 + Jj[6 + a] * r1;
+                acc[27] += 1.0;
+            }
+            double tot[28];
+            po_reduce(acc, 28, s, tot);
+            if (tot[27] == 0.0) break;
+            double H[36], b[6];
+            {
+                int q = 0;
+                for (int a = 0; a < 6; a++)
+                    for (int c = a; c < 6; c++) {
+                        H[a * 6 + c] = tot[q];
+                        H[c * 6 + a] = tot[q];
+                        q++;
+                    }
+                for (int a = 0; a < 6; a++) b[a] = tot[21 + a];
+            }
+            if (k == 0) {
+                double m = 0;
+                for (int j = 0; j < 6; j++) m = fmax(m, fabs(H[j * 7]));
+                lambda = 1e-5 * m;
+                ni = 2;
+            }
+            double rho = 0;
+            int qmax = 0;
+            do {
+                /* every thread solves the same 6x6 system redundantly (uniform, no broadcast needed) */
+                double A[36], x[6];
+                for (int i = 0; i < 36; i++) A[i] = H[i];
+                for (int j = 0; j < 6; j++) A[j * 7] += lambda;
+                bool ok2 = true;
+                for (int j = 0; j < 6; j++) {
+                    double d = A[j * 6 + j];
+                    for (int kk = 0; kk < j; kk++) d -= A[j * 6 + kk] * A[j * 6 + kk];
+                    if (!(d > 0) || !isfinite(d)) {
+                        ok2 = false;
+                        break;
+                    }
+                    d = sqrt(d);
+                    A[j * 6 + j] = d;
+                    for (int i = j + 1; i < 6; i++) {
+                        double v = A[i * 6 + j];
+                        for (int kk = 0; kk < j; kk++) v -= A[i * 6 + kk] * A[j * 6 + kk];
+                        A[i * 6 + j] = v / d;
+                    }
+                }
+                if (ok2) {
+                    for (int i = 0; i < 6; i++) {
+                        double v = b[i];
+                        for (int kk = 0; kk < i; kk++) v -= A[i * 6 + kk] * x[kk];
+                        x[i] = v / A[i * 6 + i];
+                    }
+                    for (int i = 5; i >= 0; i--) {
+                        double v = x[i];
+                        for (int kk = i + 1; kk < 6; kk++) v -= A[kk * 6 + i] * x[kk];
+                        x[i] = v / A[i * 6 + i];
+                    }
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    if (ok2)
+                        se3_exp_mul(x, s.pose, s.trial);
+                    else
+                        for (int i = 0; i < 7; i++) s.trial[i] = s.pose[i];
+                }
+                __syncthreads();
+                double tempChi = po_chi2(s.trial, xw, obs, info, fl, n, fx, fy, cx, cy, delta, s);
+                if (!ok2) tempChi = 1.7976931348623157e308;
+                double scale = 0;
+                if (ok2)
+                    for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + b[j]);
+                scale += 1e-3;
+                rho = (currentChi - tempChi) / scale;
+                if (rho > 0 && isfinite(tempChi)) {
+                    double alpha = 1. - pow((2 * rho - 1), 3);
+                    alpha = fmin(alpha, 2. / 3.);
+                    lambda *= fmax(1. / 3., alpha);
+                    ni = 2;
+                    currentChi = tempChi;
+                    __syncthreads();
+                    if (tid < 7) s.pose[tid] = s.trial[tid];
+                    __syncthreads();
+                } else {
+                    lambda *= ni;
+                    ni *= 2;
+                }
+                qmax++;
+            } while (rho < 0 && qmax < 10);
+            if (qmax == 10 || rho == 0) ok = false;
+        }
+        /* relabel (:218-244) */
+        double bad = 0;
+        for (int i = tid; i < n; i += PO_T) {
+            double e[2], pc[3];
+            project_err(s.pose, xw + (int64_t)i * 3, obs + (int64_t)i * 2, fx, fy, cx, cy, e, pc);
+            const double c = (e[0] * e[0] + e[1] * e[1]) * info[i];
+            uint8_t f = fl[i];
+            if (c > 5.991) {
+                f &= ~1;
+                outlier[i] = 1;
+                bad += 1.0;
+            } else {
+                f |= 1;
+                outlier[i] = 0;
+            }
+            if (it == 2) f &= ~2;
+            fl[i] = f;
+        }
+        double tb;
+        po_reduce(&bad, 1, s, &tb);
+        nBads = (int)tb;
+        __syncthreads();
+        if (n < 10) break;
+    }
+    if (tid < 7) pose7[tid] = s.pose[tid];
+    if (tid == 0) *n_inliers = n - nBads;
+}
+
+extern "C" int ba_pose_optimization(BASolver *s, double *pose, const double *xw, const double *obs, const double *inv_sigma2,
+                                    int n, double fx, double fy, double cx, double cy, uint8_t *outlier, int32_t *n_inliers) {
+    if (!s || !pose || !n_inliers || n < 0 || (n > 0 && (!xw || !obs || !inv_sigma2 || !outlier))) return ORB_E_INVALID;
+    *n_inliers = 0;
+    if (n < 3) return ORB_OK; /* src/Optimizer.cpp:206-207 */
+    BCHK(hipSetDevice(s->device));
+    int rc;
+    const size_t nd = 8 + (size_t)n * 6 + 2, nb = (size_t)n * 2 + 16;
+    if ((rc = ba_grow(s->dD, s->capD, nd))) return rc;
+    if ((rc = ba_grow(s->dB, s->capB, nb))) return rc;
+    if ((rc = ba_grow(s->dI, s->capI, 4))) return rc;
+    double *d_pose = s->dD, *d_xw = s->dD + 8, *d_obs = d_xw + (size_t)n * 3, *d_info = d_obs + (size_t)n * 2;
+    uint8_t *d_fl = s->dB, *d_out = s->dB + n;
+    BCHK(hipMemcpyAsync(d_pose, pose, 7 * 8, hipMemcpyHostToDevice, s->stream));
+    BCHK(hipMemcpyAsync(d_xw, xw, (size_t)n * 24, hipMemcpyHostToDevice, s->stream));
+    BCHK(hipMemcpyAsync(d_obs, obs, (size_t)n * 16, hipMemcpyHostToDevice, s->stream));
+    BCHK(hipMemcpyAsync(d_info, inv_sigma2, (size_t)n * 8, hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(k_pose_opt, dim3(1), dim3(PO_T), 0, s->stream, d_pose, (const double *)d_xw, (const double *)d_obs,
+                       (const double *)d_info, d_fl, d_out, n, fx, fy, cx, cy, s->dI);
+    BCHK(hipGetLastError());
+    BCHK(hipMemcpyAsync(pose, d_pose, 7 * 8, hipMemcpyDeviceToHost, s->stream));
+    BCHK(hipMemcpyAsync(outlier, d_out, (size_t)n, hipMemcpyDeviceToHost, s->stream));
+    BCHK(hipMemcpyAsync(n_inliers, s->dI, 4, hipMemcpyDeviceToHost, s->stream));
+    BCHK(hipStreamSynchronize(s->stream));
+    return ORB_OK;
+}

@@ -1,0 +1,112 @@
+"""Host-side mirror of ORBSlam::Optimizer (reference include/Optimizer.h:8-20) over the C-ABI.
+
+The reference's static methods walk KeyFrame / MapPoint objects (src/Optimizer.cpp:43-122); here the
+same graph is handed over as flat arrays (the BAProblem of include/orbslam_amd.h) -- the C++ shim in
+include/orbslam_amd/Optimizer.h does that flattening for real KeyFrame* / MapPoint* containers.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import BAProblem, BAResult, check, ptr
+
+HUBER_2D = float(np.sqrt(5.99))  # thHuber2D, src/Optimizer.cpp:61
+CHI2_2D = 5.991
+
+
+class Optimizer:
+    """all-static in the reference; one instance here owns a device solver handle"""
+
+    def __init__(self, max_cams=128, max_points=8192, max_obs=65536, max_batch=1, device=0):
+        self._L = _lib.lib()
+        self._s = C.c_void_p()
+        check(self._L.ba_create(max_cams, max_points, max_obs, max_batch, device, C.byref(self._s)))
+
+    def close(self):
+        if getattr(self, "_s", None) and self._s.value:
+            self._L.ba_destroy(self._s)
+            self._s = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _fill(P, w, rounds, robust, chi2_threshold, drop_robust_after, stop):
+        keep = dict(poses=np.ascontiguousarray(w["poses"], np.float64),
+                    fixed=np.ascontiguousarray(w["fixed"], np.uint8),
+                    points=np.ascontiguousarray(w["points"], np.float64),
+                    obs=np.ascontiguousarray(w["obs"], np.float64),
+                    cam_idx=np.ascontiguousarray(w["cam_idx"], np.int32),
+                    pt_idx=np.ascontiguousarray(w["pt_idx"], np.int32),
+                    inv_sigma2=np.ascontiguousarray(w["inv_sigma2"], np.float64))
+        P.n_cams, P.n_points, P.n_obs = len(keep["poses"]), len(keep["points"]), len(keep["obs"])
+        for k, v in keep.items():
+            setattr(P, k, v.ctypes.data)
+        P.fx, P.fy, P.cx, P.cy = w["fx"], w["fy"], w["cx"], w["cy"]
+        P.huber_delta = HUBER_2D if robust else 0.0
+        P.n_rounds = len(rounds)
+        for i, r in enumerate(rounds):
+            P.rounds[i] = int(r)
+        P.chi2_threshold = chi2_threshold
+        P.drop_robust_after = drop_robust_after
+        P.stop = stop.ctypes.data if stop is not None else None
+        return keep
+
+    def solve_batch(self, windows, rounds, robust=True, chi2_threshold=CHI2_2D, drop_robust_after=0, stop=None):
+        n = len(windows)
+        Ps = (BAProblem * n)()
+        Rs = (BAResult * n)()
+        keep, outs = [], []
+        for i, w in enumerate(windows):
+            keep.append(self._fill(Ps[i], w, rounds, robust, chi2_threshold, drop_robust_after, stop))
+            o = dict(poses=np.zeros((Ps[i].n_cams, 7)), points=np.zeros((Ps[i].n_points, 3)),
+                     outlier=np.zeros(max(Ps[i].n_obs, 1), np.uint8))
+            Rs[i].poses, Rs[i].points, Rs[i].outlier = o["poses"].ctypes.data, o["points"].ctypes.data, \
+                o["outlier"].ctypes.data
+            outs.append(o)
+        check(self._L.ba_solve_batch(self._s, Ps, Rs, n))
+        for i, o in enumerate(outs):
+            o["outlier"] = o["outlier"][:Ps[i].n_obs]
+            o.update(chi2_initial=Rs[i].chi2_initial, chi2_final=Rs[i].chi2_final, iterations=Rs[i].iterations,
+                     lin_solves=Rs[i].lin_solves)
+        del keep
+        return outs
+
+    # ---- the reference's entry points (include/Optimizer.h:11-19) ----
+    def BundleAdjustment(self, window, nIterations=5, pbStopFlag=None, nLoopKF=0, bRobust=True):
+        """src/Optimizer.cpp:23-129: one optimize(nIterations), robust kernel if bRobust"""
+        return self.solve_batch([window], (nIterations,), robust=bRobust, stop=pbStopFlag)[0]
+
+    def GlobalBundleAdjustemnt(self, window, nIterations=5, pbStopFlag=None, nLoopKF=0, bRobust=True):
+        """src/Optimizer.cpp:14-21 (sic: the reference's spelling, called at src/Tracking.cpp:254)"""
+        return self.BundleAdjustment(window, nIterations, pbStopFlag, nLoopKF, bRobust)
+
+    def LocalBundleAdjustment(self, window, pbStopFlag=None):
+        """a14 (absent from the reference, upstream ORB-SLAM2 schedule): 5 its -> drop chi2 > 5.991 or
+        negative-depth edges and the robust kernel -> 10 its"""
+        return self.solve_batch([window], (5, 10), robust=True, stop=pbStopFlag)[0]
+
+    def PoseOptimization(self, pose, xw, obs, inv_sigma2, fx, fy, cx, cy):
+        """src/Optimizer.cpp:131-261.  Returns (pose[7], outlier[n], n_inliers)."""
+        pose = np.ascontiguousarray(pose, np.float64).copy()
+        xw = np.ascontiguousarray(xw, np.float64)
+        obs = np.ascontiguousarray(obs, np.float64)
+        inv_sigma2 = np.ascontiguousarray(inv_sigma2, np.float64)
+        n = len(xw)
+        outlier = np.zeros(max(n, 1), np.uint8)
+        ninl = C.c_int32(0)
+        check(self._L.ba_pose_optimization(self._s, ptr(pose), ptr(xw), ptr(obs), ptr(inv_sigma2), n, fx, fy, cx, cy,
+                                           ptr(outlier), C.byref(ninl)))
+        return pose, outlier[:n], ninl.value
+
+
+def solve_window(window, rounds=(5, 10), **kw):
+    o = Optimizer()
+    try:
+        return o.solve_batch([window], rounds, **kw)[0]
+    finally:
+        o.close()

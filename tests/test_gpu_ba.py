@@ -1,0 +1,110 @@
+"""GPU parity: device bundle adjustment (PCG on the Schur complement, C-ABI) vs the CPU oracle
+(dense Cholesky, g2o semantics).  Tolerance from BASELINE.json north_star: pose / point estimates
+within 1e-5 relative on identical inputs (f64 on both sides)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+REL = 1e-5
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def opt():
+    import orbslam_in_practice_amd as oa
+    o = oa.Optimizer(max_cams=128, max_points=8192, max_obs=65536, max_batch=8)
+    yield o
+    o.close()
+
+
+@pytest.mark.parametrize("nc,npt,rounds,nfix", [(8, 150, (5, 10), 1), (50, 2000, (5, 10), 1), (50, 2000, (20,), 2),
+                                                 (100, 5000, (5, 10), 1), (100, 5000, (5, 10), 3)])
+def test_ba_matches_oracle(opt, oracle, nc, npt, rounds, nfix):
+    """nfix = 1 is the reference's graph (only KF 0 fixed, src/Optimizer.cpp:52-53: the scale gauge stays
+    free); nfix >= 2 pins the gauge like upstream's local BA (fixed covisible observers)."""
+    from orbslam_in_practice_amd import synth
+    w = synth.make_ba_window(nc * 7 + npt, nc, npt)
+    w["fixed"][:nfix] = 1
+    ref = oracle.ba_solve(w, rounds=rounds)
+    got = opt.solve_batch([w], rounds)[0]
+    assert got["iterations"] == ref["iterations"]
+    # once converged to machine precision the sign of rho is rounding noise, so the number of LM trials
+    # may differ by a few between the two solvers; the estimates may not
+    assert abs(got["lin_solves"] - ref["lin_solves"]) <= 10
+    assert np.array_equal(got["outlier"], ref["outlier"])
+    assert _rel(got["points"], ref["points"]) < REL
+    assert _rel(got["poses"][:, 4:], ref["poses"][:, 4:]) < REL
+    assert np.abs(got["poses"][:, :4] - ref["poses"][:, :4]).max() < REL
+    assert abs(got["chi2_final"] - ref["chi2_final"]) <= 1e-6 * ref["chi2_final"]
+    assert abs(got["chi2_initial"] - ref["chi2_initial"]) <= 1e-9 * ref["chi2_initial"]
+    assert got["chi2_final"] < got["chi2_initial"]
+    if len(rounds) == 2:  # outliers removed after round 0: the cost collapses
+        assert got["chi2_final"] < 0.2 * got["chi2_initial"]
+
+
+def test_ba_global_gauge_free_cost(opt, oracle):
+    """Optimizer::BundleAdjustment exactly as the reference builds it (20 robust iterations, only KF 0
+    fixed, outliers never removed).  The monocular scale gauge is free, lambda falls to ~1e-10 of the
+    Hessian diagonal and the damped system's condition number reaches ~1e10, so late iterations of ANY two
+    linear solvers part ways along the gauge orbit; what is comparable is the (gauge-invariant) cost."""
+    from orbslam_in_practice_amd import synth
+    w = synth.make_ba_window(50 * 7 + 2000, 50, 2000)
+    ref = oracle.ba_solve(w, rounds=(20,))
+    got = opt.solve_batch([w], (20,))[0]
+    assert got["iterations"] == ref["iterations"] == 20
+    assert abs(got["chi2_final"] - ref["chi2_final"]) < 1e-3 * ref["chi2_final"]
+
+
+def test_ba_batch_equals_single(opt, oracle):
+    from orbslam_in_practice_amd import synth
+    ws = [synth.make_ba_window(100 + i, 12 + i, 300 + 40 * i) for i in range(5)]
+    batch = opt.solve_batch(ws, (5, 10))
+    for w, b in zip(ws, batch):
+        single = opt.solve_batch([w], (5, 10))[0]
+        assert np.array_equal(single["points"], b["points"])  # bit-reproducible: no atomics
+        ref = oracle.ba_solve(w, rounds=(5, 10))
+        assert _rel(b["points"], ref["points"]) < REL
+
+
+def test_ba_non_robust_and_fixed_cams(opt, oracle):
+    from orbslam_in_practice_amd import synth
+    w = synth.make_ba_window(77, 20, 500, outlier_frac=0.0)
+    w["fixed"][:3] = 1  # upstream local BA: several fixed observers
+    ref = oracle.ba_solve(w, rounds=(10,), robust=False)
+    got = opt.solve_batch([w], (10,), robust=False)[0]
+    assert _rel(got["points"], ref["points"]) < REL
+    assert np.array_equal(got["poses"][:3], w["poses"][:3] * np.sign(w["poses"][:3, :1]))
+    assert got["chi2_final"] < 0.25 * got["chi2_initial"]  # no outliers: converges to the noise floor
+    assert got["chi2_final"] < 2.5 * len(w["obs"])          # ~2 dof per observation at unit-variance noise
+
+
+def test_ba_stop_flag(opt):
+    from orbslam_in_practice_amd import synth
+    import orbslam_in_practice_amd as oa
+    w = synth.make_ba_window(5, 10, 200)
+    stop = np.ones(1, np.uint8)
+    with pytest.raises(oa.OrbError) as ei:
+        opt.solve_batch([w], (5, 10), stop=stop)
+    assert ei.value.code == oa._lib.ORB_E_STOPPED
+
+
+def test_pose_optimization(opt, oracle):
+    from orbslam_in_practice_amd import synth
+    rng = np.random.default_rng(3)
+    w = synth.make_ba_window(11, 6, 400, outlier_frac=0.1)
+    c = 3
+    sel = w["cam_idx"] == c
+    xw = w["gt_points"][w["pt_idx"][sel]]
+    obs, info = w["obs"][sel], w["inv_sigma2"][sel]
+    pose0 = w["poses"][c]
+    rp, ro, rn = oracle.pose_optimization(pose0, xw, obs, info, w["fx"], w["fy"], w["cx"], w["cy"])
+    gp, go, gn = opt.PoseOptimization(pose0, xw, obs, info, w["fx"], w["fy"], w["cx"], w["cy"])
+    assert gn == rn and np.array_equal(go, ro)
+    assert np.abs(gp - rp).max() < REL * np.abs(rp).max()
+    assert 0 < gn < len(xw)
+    # fewer than 3 correspondences: returns 0 and leaves the pose alone (src/Optimizer.cpp:206-207)
+    gp2, _, gn2 = opt.PoseOptimization(pose0, xw[:2], obs[:2], info[:2], w["fx"], w["fy"], w["cx"], w["cy"])
+    assert gn2 == 0 and np.array_equal(gp2, pose0)
