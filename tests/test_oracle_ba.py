@@ -1,0 +1,100 @@
+"""CPU: pin the BA oracle -- committed golden estimates, an independent scipy least-squares optimum on the
+same problem, and the g2o building blocks (Huber, exp map) against closed forms."""
+import os
+
+import numpy as np
+import pytest
+from scipy.optimize import least_squares
+from scipy.spatial.transform import Rotation
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _window_from_golden():
+    g = np.load(os.path.join(G, "ba_golden.npz"))
+    w = {k: g[k] for k in ("poses", "fixed", "points", "obs", "cam_idx", "pt_idx", "inv_sigma2")}
+    w.update(fx=float(g["intr"][0]), fy=float(g["intr"][1]), cx=float(g["intr"][2]), cy=float(g["intr"][3]))
+    return w, g
+
+
+def test_ba_oracle_reproduces_golden(oracle):
+    w, g = _window_from_golden()
+    r = oracle.ba_solve(w, rounds=(5, 10))
+    assert np.allclose(r["poses"], g["out_poses"], rtol=0, atol=1e-9)
+    assert np.allclose(r["points"], g["out_points"], rtol=0, atol=1e-9)
+    assert np.array_equal(r["outlier"], g["out_outlier"])
+    assert r["chi2_final"] < 0.1 * r["chi2_initial"]
+
+
+def _residuals(x, w, free, act, sqrt_info):
+    poses = w["poses"].copy()
+    k = 0
+    for c in free:
+        rv = x[k:k + 3]
+        poses[c, 4:] = x[k + 3:k + 6]
+        q = Rotation.from_rotvec(rv).as_quat()  # x y z w
+        poses[c, :4] = [q[3], q[0], q[1], q[2]]
+        k += 6
+    pts = x[k:].reshape(-1, 3)
+    R = Rotation.from_quat(poses[:, [1, 2, 3, 0]]).as_matrix()
+    ci, pi = w["cam_idx"][act], w["pt_idx"][act]
+    pc = np.einsum("nij,nj->ni", R[ci], pts[pi]) + poses[ci, 4:]
+    u = w["fx"] * pc[:, 0] / pc[:, 2] + w["cx"]
+    v = w["fy"] * pc[:, 1] / pc[:, 2] + w["cy"]
+    return (np.stack([w["obs"][act, 0] - u, w["obs"][act, 1] - v], axis=1) * sqrt_info[:, None]).ravel()
+
+
+def test_ba_oracle_lands_on_the_scipy_optimum(oracle):
+    """same problem, independent optimiser: no outliers, no robust kernel, gauge pinned by two fixed
+    cameras -> both must reach the same minimiser"""
+    from orbslam_in_practice_amd import synth
+    w = synth.make_ba_window(31, 6, 60, outlier_frac=0.0)
+    w["fixed"][:2] = 1
+    r = oracle.ba_solve(w, rounds=(40,), robust=False)
+    free = [c for c in range(6) if not w["fixed"][c]]
+    act = np.arange(len(w["obs"]))
+    x0 = []
+    for c in free:
+        q = w["poses"][c, :4]
+        x0 += list(Rotation.from_quat([q[1], q[2], q[3], q[0]]).as_rotvec()) + list(w["poses"][c, 4:])
+    x0 = np.array(x0 + list(w["points"].ravel()))
+    sol = least_squares(_residuals, x0, args=(w, free, act, np.sqrt(w["inv_sigma2"])), method="trf", xtol=1e-14,
+                        ftol=1e-14, gtol=1e-12, max_nfev=400)
+    assert abs(2 * sol.cost - r["chi2_final"]) < 1e-6 * r["chi2_final"]
+    pts = sol.x[len(free) * 6:].reshape(-1, 3)
+    # points seen from >= 4 cameras are well conditioned (a 2-view point on a 5-degree baseline has an almost
+    # flat depth valley where two optimisers may stop at different depths for the same cost)
+    nobs = np.bincount(w["pt_idx"], minlength=len(pts))
+    good = nobs >= 4
+    assert good.sum() > 20
+    assert np.abs(pts[good] - r["points"][good]).max() < 1e-5 * np.abs(pts).max()
+    for k, c in enumerate(free):
+        assert np.abs(sol.x[k * 6 + 3:k * 6 + 6] - r["poses"][c, 4:]).max() < 1e-5
+
+
+def test_ba_oracle_schedules_and_outliers(oracle):
+    from orbslam_in_practice_amd import synth
+    w = synth.make_ba_window(8, 10, 250)
+    loc = oracle.ba_solve(w, rounds=(5, 10))
+    glo = oracle.ba_solve(w, rounds=(20,))
+    assert loc["iterations"] == 15 and glo["iterations"] == 20
+    assert glo["outlier"].sum() == 0                      # BundleAdjustment never switches edges off
+    frac = loc["outlier"].mean()
+    assert 0.05 < frac < 0.2                              # 5 % gross outliers + the chi2 tail
+    assert loc["chi2_final"] < loc["chi2_initial"] and glo["chi2_final"] < glo["chi2_initial"]
+    # fixed vertex does not move (src/Optimizer.cpp:52-53)
+    q0 = w["poses"][0] * (1 if w["poses"][0, 0] >= 0 else -1)
+    assert np.allclose(loc["poses"][0], q0, atol=1e-15)
+
+
+def test_pose_optimization_oracle(oracle):
+    from orbslam_in_practice_amd import synth
+    w = synth.make_ba_window(12, 5, 300, outlier_frac=0.1)
+    c = 2
+    sel = w["cam_idx"] == c
+    xw, obs, info = w["gt_points"][w["pt_idx"][sel]], w["obs"][sel], w["inv_sigma2"][sel]
+    pose, outl, ninl = oracle.pose_optimization(w["poses"][c], xw, obs, info, w["fx"], w["fy"], w["cx"], w["cy"])
+    assert ninl == len(xw) - outl.sum() and 0 < outl.sum() < 0.3 * len(xw)
+    assert np.abs(pose[4:] - w["gt_poses"][c, 4:]).max() < np.abs(w["poses"][c, 4:] - w["gt_poses"][c, 4:]).max()
+    p2, o2, n2 = oracle.pose_optimization(w["poses"][c], xw[:2], obs[:2], info[:2], w["fx"], w["fy"], w["cx"], w["cy"])
+    assert n2 == 0 and np.array_equal(p2, w["poses"][c])  # < 3 correspondences (src/Optimizer.cpp:206-207)
