@@ -85,6 +85,7 @@ struct MatchArgs {
     int32_t *matches12;      /* [pair][cap]                                */
     int32_t *nmatches;       /* [pair]                                     */
     uint8_t *bin_scratch;    /* [pair][cap] rotation bin of each i1        */
+    ulonglong2 *knn;         /* [pair][cap][2] phase-1 result: the 4 smallest keys (dist<<32 | ord), ~0 = none */
 };
 
 __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
@@ -104,7 +105,90 @@ __device__ __forceinline__ int wave_min_i32(int v) {
     return v;
 }
 
-/* one wavefront per frame pair; dynamic LDS: per F2 keypoint {float x,y; u32 ord; i32 m21; u16 mdist} */
+
+/* candidate order key of one F2 keypoint (see file header); 0xFFFFFFFF = never a candidate */
+__device__ __forceinline__ uint32_t f2_order_key(const OrbKeyPoint &kp, int j, bool brute, float min_x, float min_y,
+                                                 float invW, float invH) {
+    if (brute) return (uint32_t)j;
+    if (kp.octave != 0) return 0xFFFFFFFFu; /* GetFeaturesInArea(.., level1, level1) with level1 == 0 */
+    const int ix = (int)round(((double)kp.x - (double)min_x) * (double)invW);
+    const int iy = (int)round(((double)kp.y - (double)min_y) * (double)invH);
+    if (ix >= 0 && ix < GRID_COLS && iy >= 0 && iy < GRID_ROWS) return ((uint32_t)(ix * GRID_ROWS + iy) << 16) | (uint32_t)j;
+    return 0xFFFFFFFFu;
+}
+
+/* PHASE 1 (fully parallel): for every query i1 the FOUR smallest (dist, order) keys over ALL its window
+ * candidates, ignoring the greedy vMatchedDistance filter.  One query per lane, F2 streamed through LDS in
+ * 512-keypoint tiles (descriptors + positions + order keys), every LDS read a wave-wide broadcast. */
+#define MK_TILE 512
+__global__ __launch_bounds__(256) void k_match_knn(MatchArgs A) {
+    __shared__ uint4 s_d[MK_TILE * 2];
+    __shared__ float s_x[MK_TILE], s_y[MK_TILE];
+    __shared__ uint32_t s_o[MK_TILE];
+    const int pair = blockIdx.y;
+    const int fa = A.pair_a ? A.pair_a[pair] : 2 * pair, fb = A.pair_b ? A.pair_b[pair] : 2 * pair + 1;
+    const int n1 = A.counts[fa], n2 = A.counts[fb];
+    if ((int)(blockIdx.x * 256) >= n1) return; /* whole block beyond the query count (uniform) */
+    const OrbKeyPoint *k1 = A.kps + (size_t)fa * A.cap, *k2 = A.kps + (size_t)fb * A.cap;
+    const uint8_t *D1 = A.desc + (size_t)fa * A.cap * 32, *D2 = A.desc + (size_t)fb * A.cap * 32;
+    const bool brute = A.window < 0;
+    const float invW = (float)GRID_COLS / (A.max_x - A.min_x), invH = (float)GRID_ROWS / (A.max_y - A.min_y);
+    const float r = (float)A.window;
+    const int i1 = blockIdx.x * 256 + threadIdx.x;
+    uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float px = 0, py = 0;
+    bool active = false;
+    if (i1 < n1) {
+        const OrbKeyPoint kp1 = k1[i1];
+        active = brute || kp1.octave == 0; /* :26-28 */
+        px = kp1.x;
+        py = kp1.y;
+        if (A.prev_xy) {
+            px = A.prev_xy[((size_t)pair * A.cap + i1) * 2];
+            py = A.prev_xy[((size_t)pair * A.cap + i1) * 2 + 1];
+        }
+        const uint4 *p = (const uint4 *)(D1 + (size_t)i1 * 32);
+        uint4 v0 = p[0], v1 = p[1];
+        a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w;
+        a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
+    }
+    uint64_t b0 = ~0ull, b1 = ~0ull, b2 = ~0ull, b3 = ~0ull; /* four smallest keys, ascending */
+    for (int t0 = 0; t0 < n2; t0 += MK_TILE) {
+        const int nt = min(MK_TILE, n2 - t0);
+        __syncthreads();
+        const uint4 *src = (const uint4 *)(D2 + (size_t)t0 * 32);
+        for (int i = threadIdx.x; i < nt * 2; i += 256) s_d[i] = src[i];
+        for (int i = threadIdx.x; i < nt; i += 256) {
+            const OrbKeyPoint kp = k2[t0 + i];
+            s_x[i] = kp.x;
+            s_y[i] = kp.y;
+            s_o[i] = f2_order_key(kp, t0 + i, brute, A.min_x, A.min_y, invW, invH);
+        }
+        __syncthreads();
+        if (active) {
+            for (int j = 0; j < nt; j++) {
+                const uint32_t ord = s_o[j];
+                bool cand = ord != 0xFFFFFFFFu;
+                if (!brute) cand = cand && fabsf(s_x[j] - px) < r && fabsf(s_y[j] - py) < r;
+                const int d = hamming256(a, s_d[2 * j], s_d[2 * j + 1]);
+                const uint64_t key = cand ? (((uint64_t)(uint32_t)d << 32) | ord) : ~0ull;
+                if (key < b3) { /* insert into the sorted quadruple (keys are unique) */
+                    const bool l2 = key < b2, l1 = key < b1, l0 = key < b0;
+                    b3 = l2 ? b2 : key;
+                    b2 = l1 ? b1 : (l2 ? key : b2);
+                    b1 = l0 ? b0 : (l1 ? key : b1);
+                    b0 = l0 ? key : b0;
+                }
+            }
+        }
+    }
+    if (i1 < n1) {
+        A.knn[((size_t)pair * A.cap + i1) * 2] = make_ulonglong2(b0, b1);
+        A.knn[((size_t)pair * A.cap + i1) * 2 + 1] = make_ulonglong2(b2, b3);
+    }
+}
+
+/* PHASE 2 (serial resolution) -- one wavefront per frame pair; dynamic LDS: per F2 keypoint {float x,y; u32 ord; i32 m21; u16 mdist} */
 __global__ __launch_bounds__(64) void k_match_init(MatchArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int pair = blockIdx.x, lane = threadIdx.x;
@@ -127,15 +211,7 @@ __global__ __launch_bounds__(64) void k_match_init(MatchArgs A) {
         const OrbKeyPoint kp = k2[j];
         s_x[j] = kp.x;
         s_y[j] = kp.y;
-        uint32_t ord = 0xFFFFFFFFu;
-        if (brute) {
-            ord = (uint32_t)j;
-        } else if (kp.octave == 0) { /* GetFeaturesInArea(.., level1, level1) with level1 == 0 */
-            const int ix = (int)round(((double)kp.x - (double)A.min_x) * (double)invW);
-            const int iy = (int)round(((double)kp.y - (double)A.min_y) * (double)invH);
-            if (ix >= 0 && ix < GRID_COLS && iy >= 0 && iy < GRID_ROWS)
-                ord = ((uint32_t)(ix * GRID_ROWS + iy) << 16) | (uint32_t)j;
-        }
+        const uint32_t ord = f2_order_key(kp, j, brute, A.min_x, A.min_y, invW, invH);
         s_ord[j] = ord;
         s_m21[j] = -1;
         s_md[j] = 0xFFFF;
@@ -148,10 +224,51 @@ __global__ __launch_bounds__(64) void k_match_init(MatchArgs A) {
     __syncthreads();
     const float r = (float)A.window;
     const float factor = HISTO_LENGTH / 360.0f;
-    for (int i1 = 0; i1 < n1; i1++) {
-        const OrbKeyPoint kp1 = k1[i1];
-        if (!brute && kp1.octave > 0) continue;
-        float px = kp1.x, py = kp1.y;
+    const ulonglong2 *knn = A.knn + (size_t)pair * A.cap * 2;
+    for (int base = 0; base < n1; base += 64) {
+      /* prefetch the phase-1 result of 64 queries (one per lane), then walk them in order */
+      ulonglong2 m01 = make_ulonglong2(~0ull, ~0ull), m23 = m01;
+      if (base + lane < n1) {
+          m01 = knn[(size_t)(base + lane) * 2];
+          m23 = knn[(size_t)(base + lane) * 2 + 1];
+      }
+      const int nchunk = min(64, n1 - base);
+      for (int t = 0; t < nchunk; t++) {
+        const int i1 = base + t;
+        uint64_t c[4];
+        c[0] = __shfl(m01.x, t);
+        if (c[0] == ~0ull) continue; /* no candidate at all (or octave > 0): nothing can match, no state change */
+        c[1] = __shfl(m01.y, t);
+        c[2] = __shfl(m23.x, t);
+        c[3] = __shfl(m23.y, t);
+        /* the filtered candidate set (:49-50) is a subset of the unfiltered one, so its two smallest keys are
+           the first two ALLOWED entries of the sorted unfiltered list -- if they show up within the top 4 */
+        uint64_t gKey = ~0ull;
+        int bestDist2 = 0x7FFFFFFF;
+        int found = 0;
+        bool complete = false; /* the top-4 list is the whole candidate set */
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (c[k] == ~0ull) {
+                complete = true;
+                break;
+            }
+            const int jk = (int)(c[k] & 0xFFFFu), dk = (int)(c[k] >> 32);
+            const int mdk = s_md[jk] == 0xFFFF ? 0x7FFFFFFF : (int)s_md[jk];
+            if (!(mdk <= dk)) {
+                if (found == 0)
+                    gKey = c[k];
+                else if (found == 1)
+                    bestDist2 = dk;
+                found++;
+                if (found == 2) break;
+            }
+        }
+        const bool fast = found == 2 || complete;
+        if (fast) {
+        } else {
+        const OrbKeyPoint kp1s = k1[i1];
+        float px = kp1s.x, py = kp1s.y;
         if (A.prev_xy) {
             px = A.prev_xy[((size_t)pair * A.cap + i1) * 2];
             py = A.prev_xy[((size_t)pair * A.cap + i1) * 2 + 1];
@@ -186,9 +303,10 @@ __global__ __launch_bounds__(64) void k_match_init(MatchArgs A) {
                 }
             }
         }
-        const uint64_t gKey = wave_min_u64(bestKey);
+        gKey = wave_min_u64(bestKey);
         const int alt = (bestKey == gKey) ? second : (bestKey == ~0ull ? 0x7FFFFFFF : (int)(bestKey >> 32));
-        const int bestDist2 = wave_min_i32(alt);
+        bestDist2 = wave_min_i32(alt);
+        }
         if (gKey != ~0ull) {
             const int bestDist = (int)(gKey >> 32);
             const int bestIdx2 = (int)(gKey & 0xFFFFu);
@@ -200,7 +318,7 @@ __global__ __launch_bounds__(64) void k_match_init(MatchArgs A) {
                     s_m21[bestIdx2] = i1;
                     s_md[bestIdx2] = (uint16_t)bestDist;
                     if (A.check_ori) {
-                        float rot = kp1.angle - k2[bestIdx2].angle;
+                        float rot = k1[i1].angle - k2[bestIdx2].angle;
                         if (rot < 0.0f) rot += 360.0f;
                         int bin = (int)roundf(rot * factor);
                         if (bin == HISTO_LENGTH) bin = 0;
@@ -210,7 +328,8 @@ __global__ __launch_bounds__(64) void k_match_init(MatchArgs A) {
                 }
             }
         }
-        __syncthreads(); /* lane 0's LDS updates before the next scan (single-wave workgroup) */
+        __syncthreads(); /* lane 0's LDS updates before the next query (single-wave workgroup) */
+      }
     }
     /* nmatches == number of i1 with m12 >= 0 (every accept adds one and every steal removes one) */
     __threadfence_block();
@@ -285,6 +404,7 @@ struct OrbMatcher {
     int32_t *d_m12 = nullptr;     /* [max_pairs][max_kp] */
     int32_t *d_nm = nullptr;      /* [max_pairs] */
     uint8_t *d_bins = nullptr;    /* [max_pairs][max_kp] */
+    ulonglong2 *d_knn = nullptr;  /* [max_pairs][max_kp] */
     int32_t *d_idx = nullptr;
     uint16_t *d_best = nullptr, *d_second = nullptr;
     bool profile = false;
@@ -310,6 +430,7 @@ extern "C" int orb_matcher_create(int max_keypoints, int max_pairs, int device_i
         hipMalloc((void **)&m->d_m12, (size_t)max_pairs * K * 4) != hipSuccess ||
         hipMalloc((void **)&m->d_nm, (size_t)max_pairs * 4) != hipSuccess ||
         hipMalloc((void **)&m->d_bins, (size_t)max_pairs * K) != hipSuccess ||
+        hipMalloc((void **)&m->d_knn, (size_t)max_pairs * K * 2 * sizeof(ulonglong2)) != hipSuccess ||
         hipMalloc((void **)&m->d_idx, K * 4) != hipSuccess || hipMalloc((void **)&m->d_best, K * 2) != hipSuccess ||
         hipMalloc((void **)&m->d_second, K * 2) != hipSuccess) {
         orb_matcher_destroy(m);
@@ -331,6 +452,7 @@ extern "C" void orb_matcher_destroy(OrbMatcher *m) {
     (void)hipFree(m->d_m12);
     (void)hipFree(m->d_nm);
     (void)hipFree(m->d_bins);
+    (void)hipFree(m->d_knn);
     (void)hipFree(m->d_idx);
     (void)hipFree(m->d_best);
     (void)hipFree(m->d_second);
@@ -448,6 +570,8 @@ static int launch_match(const MatchArgs &A, int n_pairs, hipStream_t st) {
         MCHK(hipFuncSetAttribute((const void *)k_match_init, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = lds;
     }
+    hipLaunchKernelGGL(k_match_knn, dim3((A.cap + 255) / 256, n_pairs), dim3(256), 0, st, A);
+    MCHK(hipGetLastError());
     hipLaunchKernelGGL(k_match_init, dim3(n_pairs), dim3(64), lds, st, A);
     MCHK(hipGetLastError());
     return ORB_OK;
@@ -493,6 +617,7 @@ extern "C" int orb_match_init(OrbMatcher *m, const OrbFrameView *f1, const OrbFr
     A.matches12 = m->d_m12;
     A.nmatches = m->d_nm;
     A.bin_scratch = m->d_bins;
+    A.knn = m->d_knn;
     int rc = launch_match(A, 1, m->stream);
     if (rc) return rc;
     MCHK(hipMemcpyAsync(matches12, m->d_m12, (size_t)f1->n * 4, hipMemcpyDeviceToHost, m->stream));
@@ -532,6 +657,7 @@ extern "C" int orb_match_batch_device(OrbMatcher *m, const OrbKeyPoint *d_kps, c
     A.matches12 = d_matches12;
     A.nmatches = d_nmatches;
     A.bin_scratch = m->d_bins;
+    A.knn = m->d_knn;
     hipStream_t st = stream ? (hipStream_t)stream : m->stream;
     hipEvent_t *ev = m->ev[m->prof_calls % OrbMatcher::kProfRing];
     if (m->profile) MCHK(hipEventRecord(ev[0], st));
