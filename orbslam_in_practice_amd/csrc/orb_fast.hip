@@ -21,6 +21,12 @@
 
 #define FT_LD 68 /* LDS row pitch */
 
+typedef short v2s __attribute__((ext_vector_type(2)));
+
+/* cornerScore of one pixel.  Both ring polarities ride in one packed register: element k holds
+ * (d[k], -d[k]) with d = v - ring[k]; the max over the 16 nine-arcs of the arc minimum is then the "dark"
+ * score in the low half and the "bright" score in the high half, so ONE log-step sliding-minimum network of
+ * v_pk_min_i16 / v_pk_max_i16 serves both (windows of 2, 4, 8 and then 9 ring pixels). */
 __device__ __forceinline__ int fast_score16(const uint8_t *c, int v) {
     /* ring in OpenCV's order: (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)
        (-3,0)(-3,1)(-2,2)(-1,3) */
@@ -41,34 +47,30 @@ __device__ __forceinline__ int fast_score16(const uint8_t *c, int v) {
     d[13] = v - c[1 * FT_LD - 3];
     d[14] = v - c[2 * FT_LD - 2];
     d[15] = v - c[3 * FT_LD - 1];
-    /* max over the 16 nine-arcs of min(d) (dark ring) and of min(-d) (bright ring): log-step windows */
-    int lo2[16], hi2[16];
+    v2s p[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        lo2[k] = min(d[k], d[(k + 1) & 15]);
-        hi2[k] = max(d[k], d[(k + 1) & 15]);
+        p[k].x = (short)d[k];
+        p[k].y = (short)(-d[k]);
     }
-    int lo4[16], hi4[16];
+    v2s w2[16], w4[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) w2[k] = __builtin_elementwise_min(p[k], p[(k + 1) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) w4[k] = __builtin_elementwise_min(w2[k], w2[(k + 2) & 15]);
+    v2s best = {-1000, -1000};
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        lo4[k] = min(lo2[k], lo2[(k + 2) & 15]);
-        hi4[k] = max(hi2[k], hi2[(k + 2) & 15]);
+        v2s w9 = __builtin_elementwise_min(__builtin_elementwise_min(w4[k], w4[(k + 4) & 15]), p[(k + 8) & 15]);
+        best = __builtin_elementwise_max(best, w9);
     }
-    int a = -1000, b = 1000;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
-        int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
-        a = max(a, lo9);
-        b = min(b, hi9);
-    }
-    return max(a, -b) - 1;
+    return max((int)best.x, (int)best.y) - 1;
 }
 
-__global__ __launch_bounds__(256) void k_fast_cells(OrbGeom g, const uint8_t *pyr, const CellDesc *cells,
+__global__ __launch_bounds__(256, 8) void k_fast_cells(OrbGeom g, const uint8_t *pyr, const CellDesc *cells,
                                                      uint32_t *slab, int32_t *cell_cnt) {
-    __shared__ uint8_t s_px[ORB_CELL_MAX][FT_LD];
-    __shared__ uint8_t s_sc[ORB_CELL_MAX][FT_LD];
+    __shared__ __attribute__((aligned(16))) uint8_t s_px[ORB_CELL_MAX][FT_LD];
+    __shared__ __attribute__((aligned(16))) uint8_t s_sc[ORB_CELL_MAX][FT_LD];
     __shared__ int s_wave[4];
     __shared__ int s_any;
     const int cell = blockIdx.x, frame = blockIdx.y;
@@ -82,14 +84,17 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbGeom g, const uint8_t *py
         const uint8_t *row = src + (int64_t)r * L.pitch;
         for (int c = lane; c < rw; c += 64) s_px[r][c] = row[c];
     }
-    for (int i = tid; i < ORB_CELL_MAX * FT_LD; i += 256) (&s_sc[0][0])[i] = 0;
+    for (int i = tid; i < ORB_CELL_MAX * FT_LD / 4; i += 256) ((uint32_t *)&s_sc[0][0])[i] = 0u;
     if (tid == 0) s_any = 0;
     __syncthreads();
     const int iw = rw - 6, ih = rh - 6; /* detection zone */
     const int n_in = (iw > 0 && ih > 0) ? iw * ih : 0;
+    /* i / iw without an integer divide: exact for i < 2^12, iw <= 59 (|error| of (i+0.5)/iw is far below 0.5/iw) */
+    const float inv_iw = 1.0f / (float)(iw > 0 ? iw : 1);
+#define DIV_IW(i) ((int)(((float)(i) + 0.5f) * inv_iw))
     /* scores (0 when not a corner at minThFAST) */
     for (int i = tid; i < n_in; i += 256) {
-        int y = i / iw, x = i - y * iw;
+        int y = DIV_IW(i), x = i - y * iw;
         const uint8_t *c = &s_px[y + 3][x + 3];
         int s = fast_score16(c, (int)c[0]);
         s_sc[y + 3][x + 3] = (uint8_t)(s >= g.min_th ? s : 0);
@@ -101,8 +106,12 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbGeom g, const uint8_t *py
     const int beg = min(tid * per, n_in), end = min(beg + per, n_in);
     int any_ini = 0;
     uint32_t keep_lo = 0; /* per <= 14 (59*59/256) : bit k = element beg+k kept */
-    for (int i = beg; i < end; i++) {
-        int y = i / iw + 3, x = i - (y - 3) * iw + 3;
+    const int y_beg = DIV_IW(beg), x_beg = beg - y_beg * iw;
+    for (int i = beg, y = y_beg + 3, x = x_beg + 3; i < end; i++, x++) {
+        if (x == iw + 3) {
+            x = 3;
+            y++;
+        }
         int s = s_sc[y][x];
         bool k = s > 0 && s > s_sc[y - 1][x - 1] && s > s_sc[y - 1][x] && s > s_sc[y - 1][x + 1] &&
                  s > s_sc[y][x - 1] && s > s_sc[y][x + 1] && s > s_sc[y + 1][x - 1] && s > s_sc[y + 1][x] &&
@@ -117,9 +126,12 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbGeom g, const uint8_t *py
     const int th = s_any ? g.ini_th : g.min_th;
     int mine = 0;
     uint32_t sel = 0;
-    for (int i = beg; i < end; i++) {
+    for (int i = beg, y = y_beg + 3, x = x_beg + 3; i < end; i++, x++) {
+        if (x == iw + 3) {
+            x = 3;
+            y++;
+        }
         if (keep_lo & (1u << (i - beg))) {
-            int y = i / iw + 3, x = i - (y - 3) * iw + 3;
             if (s_sc[y][x] >= th) {
                 sel |= 1u << (i - beg);
                 mine++;
@@ -139,9 +151,12 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbGeom g, const uint8_t *py
     for (int w = 0; w < wave; w++) base += s_wave[w];
     int pos = base + incl - mine;
     uint32_t *out = slab + (int64_t)frame * g.slab_frame_count + cd.slab_off;
-    for (int i = beg; i < end; i++) {
+    for (int i = beg, y = y_beg + 3, x = x_beg + 3; i < end; i++, x++) {
+        if (x == iw + 3) {
+            x = 3;
+            y++;
+        }
         if (sel & (1u << (i - beg))) {
-            int y = i / iw + 3, x = i - (y - 3) * iw + 3;
             out[pos++] = KEY_PACK(x + cd.offX, y + cd.offY, s_sc[y][x]);
         }
     }
