@@ -91,9 +91,13 @@ __device__ __forceinline__ int reflect101(int p, int n) {
     return p;
 }
 
+/* 64 x 32 output tile per workgroup.  Staging: rows [ty0-3, ty0+35) x bytes [tx0-4, tx0+68) as aligned
+ * dwords (18 per row, coalesced); tiles that touch the left/right image edge take the byte path with
+ * REFLECT_101 indexing.  Horizontal pass: 4 adjacent pixels per thread from 3 LDS dwords -> 4 x u16.
+ * Vertical pass: a 4-pixel x 4-row strip per thread (10 LDS reads of 8 B), one packed u32 store per row. */
 __global__ __launch_bounds__(256) void k_blur(OrbGeom g, const uint8_t *pyr, uint8_t *blur, TileMap tm) {
-    __shared__ uint8_t s_in[BL_TH + 6][BL_TW + 8];
-    __shared__ uint16_t s_h[BL_TH + 6][BL_TW];
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[BL_TH + 6][BL_TW + 8];   /* column c <-> x = tx0 - 4 + c */
+    __shared__ __attribute__((aligned(16))) uint16_t s_h[BL_TH + 6][BL_TW];
     int level = 0;
     while (level + 1 < g.nlevels && (int)blockIdx.x >= tm.prefix[level + 1]) level++;
     const LevelGeom &L = g.lv[level];
@@ -103,31 +107,74 @@ __global__ __launch_bounds__(256) void k_blur(OrbGeom g, const uint8_t *pyr, uin
     const uint8_t *src = level_ptr(pyr, g, frame, level);
     uint8_t *dst = level_ptr(blur, g, frame, level);
     const int tid = threadIdx.x;
-    for (int i = tid; i < (BL_TH + 6) * (BL_TW + 6); i += 256) {
-        int r = i / (BL_TW + 6), c = i - r * (BL_TW + 6);
-        int y = reflect101(ty0 + r - 3, L.h), x = reflect101(tx0 + c - 3, L.w);
-        s_in[r][c] = src[(int64_t)y * L.pitch + x];
+    const bool interior = tx0 >= 4 && tx0 + BL_TW + 4 <= L.w; /* every staged byte is a real pixel of its row */
+    if (interior) {
+        for (int i = tid; i < (BL_TH + 6) * 18; i += 256) {
+            const int r = i / 18, c4 = i - r * 18;
+            const int y = reflect101(ty0 + r - 3, L.h);
+            *(uint32_t *)&s_in[r][c4 * 4] = *(const uint32_t *)(src + (int64_t)y * L.pitch + (tx0 - 4) + c4 * 4);
+        }
+    } else {
+        for (int i = tid; i < (BL_TH + 6) * (BL_TW + 8); i += 256) {
+            const int r = i / (BL_TW + 8), c = i - r * (BL_TW + 8);
+            const int y = reflect101(ty0 + r - 3, L.h), x = reflect101(tx0 - 4 + c, L.w);
+            s_in[r][c] = src[(int64_t)y * L.pitch + x];
+        }
     }
     __syncthreads();
-    for (int i = tid; i < (BL_TH + 6) * BL_TW; i += 256) {
-        int r = i >> 6, c = i & 63;
-        const uint8_t *p = &s_in[r][c];
-        int s = 18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3];
-        s_h[r][c] = (uint16_t)s; /* <= 255*257 = 65535 */
-    }
-    __syncthreads();
-    const int c = tid & 63, rq = tid >> 6;
-    const int x = tx0 + c;
-    if (x >= L.w) return;
+    /* horizontal: outputs x = tx0 + 4q .. +3 need bytes (4q+1 .. 4q+10) of the staged row */
+    for (int i = tid; i < (BL_TH + 6) * 16; i += 256) {
+        const int r = i >> 4, q = i & 15;
+        const uint32_t *p = (const uint32_t *)&s_in[r][q * 4];
+        const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+        int b[12];
 #pragma unroll
-    for (int k = 0; k < BL_TH / 4; k++) {
-        int r = rq * (BL_TH / 4) + k;
-        int y = ty0 + r;
-        if (y >= L.h) break;
-        int s = 18 * ((int)s_h[r][c] + s_h[r + 6][c]) + 34 * ((int)s_h[r + 1][c] + s_h[r + 5][c]) +
-                49 * ((int)s_h[r + 2][c] + s_h[r + 4][c]) + 55 * (int)s_h[r + 3][c];
-        int v = (s + (1 << 15)) >> 16;
-        dst[(int64_t)y * L.pitch + x] = (uint8_t)(v > 255 ? 255 : v);
+        for (int k = 0; k < 4; k++) {
+            b[k] = (w0 >> (8 * k)) & 0xFF;
+            b[4 + k] = (w1 >> (8 * k)) & 0xFF;
+            b[8 + k] = (w2 >> (8 * k)) & 0xFF;
+        }
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            o[k] = 18 * (b[k + 1] + b[k + 7]) + 34 * (b[k + 2] + b[k + 6]) + 49 * (b[k + 3] + b[k + 5]) + 55 * b[k + 4];
+        *(uint2 *)&s_h[r][q * 4] = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16)); /* each <= 65535 */
+    }
+    __syncthreads();
+    /* vertical: thread -> (column group q, row group rg of 4 rows) ; 16 x 8 = 128 strips, two passes of 256 thr */
+    {
+        const int q = tid & 15, rg = tid >> 4; /* rg 0..15: rows rg*2 .. rg*2+1 */
+        const int x = tx0 + q * 4;
+        if (x < L.w) {
+            uint2 rows[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) rows[k] = *(const uint2 *)&s_h[rg * 2 + k][q * 4];
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+                const int y = ty0 + rg * 2 + rr;
+                if (y < L.h) {
+                    uint32_t packed = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        int v[7];
+#pragma unroll
+                        for (int m = 0; m < 7; m++) {
+                            const uint32_t wd = (k < 2) ? rows[rr + m].x : rows[rr + m].y;
+                            v[m] = (k & 1) ? (int)(wd >> 16) : (int)(wd & 0xFFFF);
+                        }
+                        int sum = 18 * (v[0] + v[6]) + 34 * (v[1] + v[5]) + 49 * (v[2] + v[4]) + 55 * v[3];
+                        int o = (sum + (1 << 15)) >> 16;
+                        o = o > 255 ? 255 : o;
+                        packed |= (uint32_t)o << (8 * k);
+                    }
+                    uint8_t *d = dst + (int64_t)y * L.pitch + x;
+                    if (x + 4 <= L.w)
+                        *(uint32_t *)d = packed;
+                    else
+                        for (int k = 0; x + k < L.w; k++) d[k] = (uint8_t)(packed >> (8 * k));
+                }
+            }
+        }
     }
 }
 
