@@ -22,19 +22,21 @@
  */
 #include "orb_common.h"
 
-#define QT_T ORB_QT_THREADS
-#define QT_W (QT_T / 64)
-#define MAXN ORB_QT_MAX_NODES
+/* The node-list capacity NN is a template parameter (256 / 512 / 1024, picked from the largest per-level
+ * quota); the workgroup has NN/2 threads so that the list-order scans handle two entries per thread. */
+#define QT_T (NN / 2)
+#define QT_W (NN / 128)
+#define MAXN NN
 
-struct QtLists {
+template <int NN> struct QtLists {
     short x0[2][MAXN], y0[2][MAXN], x1[2][MAXN], y1[2][MAXN];
     uint32_t start[2][MAXN];
     uint32_t cnt[2][MAXN]; /* bit 31: which key buffer holds the segment */
     uint16_t born[2][MAXN];
 };
 
-struct QtShared {
-    QtLists L;
+template <int NN> struct QtShared {
+    QtLists<NN> L;
     uint32_t ccnt[MAXN][4]; /* child key counts of candidate nodes           */
     uint16_t rnode[MAXN];   /* processing rank -> node index                 */
     uint16_t rank[MAXN];    /* node index -> processing rank (0xFFFF = none) */
@@ -57,7 +59,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
 }
 
 /* in-place inclusive scan of v[0..MAXN) (entries >= n must be 0); returns the total; all threads call */
-__device__ __forceinline__ uint32_t block_scan_incl(uint32_t *v, QtShared &s) {
+template <int NN> __device__ __forceinline__ uint32_t block_scan_incl(uint32_t *v, QtShared<NN> &s) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t a = v[2 * tid], b = v[2 * tid + 1];
     uint32_t incl = wave_incl_scan(a + b, lane);
@@ -81,7 +83,7 @@ __device__ __forceinline__ int quadrant(uint32_t key, int mx, int my) {
 
 /* one division pass.  sorted=0: OUTER, sorted=1: SORTED.  Returns the new list length, and through
  * *n_to_expand the number of new children with >1 keys.  All threads call (uniform control flow). */
-__device__ __forceinline__ int qt_pass(QtShared &s, int cur, int nn, int N, int sorted, uint32_t *keys0, uint32_t *keys1,
+template <int NN> __device__ __forceinline__ int qt_pass(QtShared<NN> &s, int cur, int nn, int N, int sorted, uint32_t *keys0, uint32_t *keys1,
                        int *n_to_expand) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nxt = cur ^ 1;
@@ -93,7 +95,7 @@ __device__ __forceinline__ int qt_pass(QtShared &s, int cur, int nn, int N, int 
     __syncthreads();
     int K;
     if (!sorted) {
-        K = (int)block_scan_incl(s.scanL, s); /* inclusive: rank = scan-1 for candidates */
+        K = (int)block_scan_incl<NN>(s.scanL, s); /* inclusive: rank = scan-1 for candidates */
         for (int e = 2 * tid; e < 2 * tid + 2; e++)
             if (e < nn && CNT(s.L.cnt[cur][e]) > 1) {
                 int r = (int)s.scanL[e] - 1;
@@ -131,14 +133,28 @@ __device__ __forceinline__ int qt_pass(QtShared &s, int cur, int nn, int N, int 
         const int n = (int)CNT(cv);
         const int mx = s.L.x0[cur][i] + ((s.L.x1[cur][i] - s.L.x0[cur][i] + 1) >> 1);
         const int my = s.L.y0[cur][i] + ((s.L.y1[cur][i] - s.L.y0[cur][i] + 1) >> 1);
+        /* private per-lane counts (packed 4 x 8 bit per batch), 8 independent loads in flight per lane */
         uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-        for (int j = 0; j < n; j += 64) {
-            int q = -1;
-            if (j + lane < n) q = quadrant(src[j + lane], mx, my);
-            c0 += __popcll(__ballot(q == 0));
-            c1 += __popcll(__ballot(q == 1));
-            c2 += __popcll(__ballot(q == 2));
-            c3 += __popcll(__ballot(q == 3));
+        for (int j = lane; j < n; j += 64 * 8) {
+            uint32_t kk[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) kk[u] = (j + u * 64 < n) ? src[j + u * 64] : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (j + u * 64 < n) {
+                    const int q = quadrant(kk[u], mx, my);
+                    c0 += q == 0;
+                    c1 += q == 1;
+                    c2 += q == 2;
+                    c3 += q == 3;
+                }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            c0 += __shfl_xor(c0, o);
+            c1 += __shfl_xor(c1, o);
+            c2 += __shfl_xor(c2, o);
+            c3 += __shfl_xor(c3, o);
         }
         if (lane == 0) {
             s.ccnt[i][0] = c0;
@@ -158,7 +174,7 @@ __device__ __forceinline__ int qt_pass(QtShared &s, int cur, int nn, int N, int 
         s.scanR[r] = nch; /* 0 beyond K */
     }
     __syncthreads();
-    block_scan_incl(s.scanR, s); /* H[r] = children of ranks 0..r */
+    block_scan_incl<NN>(s.scanR, s); /* H[r] = children of ranks 0..r */
     int m = K;
     if (sorted) {
         /* rank r is divided iff the list still has < N nodes before it: nn + (H[r-1] - r) < N */
@@ -179,7 +195,7 @@ __device__ __forceinline__ int qt_pass(QtShared &s, int cur, int nn, int N, int 
     /* undivided nodes keep their relative order behind all new children */
     for (int e = 2 * tid; e < 2 * tid + 2; e++) s.scanL[e] = (e < nn && s.rank[e] >= m) ? 1u : 0u;
     __syncthreads();
-    block_scan_incl(s.scanL, s);
+    block_scan_incl<NN>(s.scanL, s);
     for (int e = 2 * tid; e < 2 * tid + 2; e++)
         if (e < nn && s.rank[e] >= m) {
             int p = (int)Htot + (int)s.scanL[e] - 1;
@@ -221,22 +237,25 @@ __device__ __forceinline__ int qt_pass(QtShared &s, int cur, int nn, int N, int 
         const uint32_t c0 = s.ccnt[i][0], c1 = s.ccnt[i][1], c2 = s.ccnt[i][2], c3 = s.ccnt[i][3];
         uint32_t o0 = 0, o1 = c0, o2 = c0 + c1, o3 = c0 + c1 + c2;
         const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-        for (int j = 0; j < n; j += 64) {
-            int q = -1;
-            uint32_t key = 0;
-            if (j + lane < n) {
-                key = src[j + lane];
-                q = quadrant(key, mx, my);
+        for (int j0 = 0; j0 < n; j0 += 64 * 8) {
+            uint32_t kk[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) kk[u] = (j0 + u * 64 + lane < n) ? src[j0 + u * 64 + lane] : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (j0 + u * 64 >= n) break; /* wave-uniform */
+                const uint32_t key = kk[u];
+                const int q = (j0 + u * 64 + lane < n) ? quadrant(key, mx, my) : -1;
+                const uint64_t b0 = __ballot(q == 0), b1 = __ballot(q == 1), b2 = __ballot(q == 2), b3 = __ballot(q == 3);
+                if (q == 0) dst[o0 + __popcll(b0 & lt)] = key;
+                if (q == 1) dst[o1 + __popcll(b1 & lt)] = key;
+                if (q == 2) dst[o2 + __popcll(b2 & lt)] = key;
+                if (q == 3) dst[o3 + __popcll(b3 & lt)] = key;
+                o0 += __popcll(b0);
+                o1 += __popcll(b1);
+                o2 += __popcll(b2);
+                o3 += __popcll(b3);
             }
-            uint64_t b0 = __ballot(q == 0), b1 = __ballot(q == 1), b2 = __ballot(q == 2), b3 = __ballot(q == 3);
-            if (q == 0) dst[o0 + __popcll(b0 & lt)] = key;
-            if (q == 1) dst[o1 + __popcll(b1 & lt)] = key;
-            if (q == 2) dst[o2 + __popcll(b2 & lt)] = key;
-            if (q == 3) dst[o3 + __popcll(b3 & lt)] = key;
-            o0 += __popcll(b0);
-            o1 += __popcll(b1);
-            o2 += __popcll(b2);
-            o3 += __popcll(b3);
         }
         if (lane < 4) {
             const int q = lane;
@@ -260,11 +279,11 @@ __device__ __forceinline__ int qt_pass(QtShared &s, int cur, int nn, int N, int 
     return (int)Htot + (nn - m);
 }
 
-__global__ __launch_bounds__(QT_T) void k_quadtree(OrbGeom g, const CellDesc *cells, const uint32_t *slab,
+template <int NN> __global__ __launch_bounds__(NN / 2) void k_quadtree(OrbGeom g, const CellDesc *cells, const uint32_t *slab,
                                                     const int32_t *cell_cnt, uint32_t *keysA, uint32_t *keysB,
                                                     int32_t *cand_cnt, uint32_t *lvl_kp, int32_t *lvl_cnt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char qt_smem[];
-    QtShared &s = *reinterpret_cast<QtShared *>(qt_smem);
+    QtShared<NN> &s = *reinterpret_cast<QtShared<NN> *>(qt_smem);
     const int level = blockIdx.x, frame = blockIdx.y;
     const LevelGeom &L = g.lv[level];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -288,10 +307,16 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(OrbGeom g, const CellDesc *ce
             if (w < wave) base += s.wtot[w];
             tot += s.wtot[w];
         }
-        if (c < ncell) {
-            const uint32_t *src = fslab + cells[L.cell_base + c].slab_off;
-            uint32_t o = base + incl - v;
-            for (uint32_t k = 0; k < v; k++) k0[o + k] = src[k];
+        if (c < ncell) s.scanL[tid] = base + incl - v; /* exclusive prefix of this chunk's cells */
+        if (c < ncell) s.scanR[tid] = v;
+        __syncthreads();
+        {
+            const int nc = min(QT_T, ncell - c0);
+            for (int cc = wave; cc < nc; cc += QT_W) { /* one wavefront per cell: coalesced copy */
+                const uint32_t *src = fslab + cells[L.cell_base + c0 + cc].slab_off;
+                const uint32_t o = s.scanL[cc], vv = s.scanR[cc];
+                for (uint32_t k = lane; k < vv; k += 64) k0[o + k] = src[k];
+            }
         }
         run += tot;
         __syncthreads();
@@ -363,7 +388,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(OrbGeom g, const CellDesc *ce
         int guard = 0;
         while (!finish && guard++ < 64) {
             int prevSize = nn, nToExpand = 0;
-            nn = qt_pass(s, cur, nn, N, 0, k0, k1, &nToExpand);
+            nn = qt_pass<NN>(s, cur, nn, N, 0, k0, k1, &nToExpand);
             cur ^= 1;
             if (nn >= N || nn == prevSize) {
                 finish = true;
@@ -371,7 +396,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(OrbGeom g, const CellDesc *ce
                 while (!finish && guard++ < 64) {
                     prevSize = nn;
                     int dummy;
-                    nn = qt_pass(s, cur, nn, N, 1, k0, k1, &dummy);
+                    nn = qt_pass<NN>(s, cur, nn, N, 1, k0, k1, &dummy);
                     cur ^= 1;
                     if (nn >= N || nn == prevSize) finish = true;
                 }
@@ -399,17 +424,24 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(OrbGeom g, const CellDesc *ce
     if (tid == 0) lvl_cnt[(int64_t)frame * g.nlevels + level] = nn;
 }
 
-hipError_t launch_quadtree(const OrbGeom &g, const OrbBuffers &b, int n_frames, hipStream_t st) {
-    static_assert(MAXN == 2 * QT_T, "block_scan_incl scans two entries per thread");
+template <int NN> static hipError_t launch_qt(const OrbGeom &g, const OrbBuffers &b, int n_frames, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)sizeof(QtShared));
+        hipError_t e = hipFuncSetAttribute((const void *)k_quadtree<NN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)sizeof(QtShared<NN>));
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     dim3 grid(g.nlevels, n_frames);
-    hipLaunchKernelGGL(k_quadtree, grid, dim3(QT_T), sizeof(QtShared), st, g, b.cells, (const uint32_t *)b.slab,
+    hipLaunchKernelGGL(k_quadtree<NN>, grid, dim3(NN / 2), sizeof(QtShared<NN>), st, g, b.cells, (const uint32_t *)b.slab,
                        (const int32_t *)b.cell_cnt, b.keysA, b.keysB, b.cand_cnt, b.lvl_kp, b.lvl_cnt);
     return hipGetLastError();
+}
+
+hipError_t launch_quadtree(const OrbGeom &g, const OrbBuffers &b, int n_frames, hipStream_t st) {
+    int need = 0;
+    for (int l = 0; l < g.nlevels; l++) need = need > g.lv[l].out_cap ? need : g.lv[l].out_cap;
+    if (need <= 256) return launch_qt<256>(g, b, n_frames, st);
+    if (need <= 512) return launch_qt<512>(g, b, n_frames, st);
+    return launch_qt<1024>(g, b, n_frames, st);
 }
