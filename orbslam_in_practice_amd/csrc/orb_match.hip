@@ -85,7 +85,8 @@ struct MatchArgs {
     int32_t *matches12;      /* [pair][cap]                                */
     int32_t *nmatches;       /* [pair]                                     */
     uint8_t *bin_scratch;    /* [pair][cap] rotation bin of each i1        */
-    ulonglong2 *knn;         /* [pair][cap][2] phase-1 result: the 4 smallest keys (dist<<32 | ord), ~0 = none */
+    int desc_in_lds;         /* F2 descriptors staged in LDS for the (rare) rescans */
+    ulonglong2 *knn;         /* [pair][cap][MK_TOP/2] phase-1 result: the smallest keys (dist<<32 | ord), ~0 = none */
 };
 
 __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
@@ -95,6 +96,11 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
         v = t < v ? t : v;
     }
     return v;
+}
+__device__ __forceinline__ uint64_t rdlane64(uint64_t v, int lane_uniform) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane_uniform);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane_uniform);
+    return ((uint64_t)hi << 32) | lo;
 }
 __device__ __forceinline__ int wave_min_i32(int v) {
 #pragma unroll
@@ -117,10 +123,11 @@ __device__ __forceinline__ uint32_t f2_order_key(const OrbKeyPoint &kp, int j, b
     return 0xFFFFFFFFu;
 }
 
-/* PHASE 1 (fully parallel): for every query i1 the FOUR smallest (dist, order) keys over ALL its window
+/* PHASE 1 (fully parallel): for every query i1 the MK_TOP smallest (dist, order) keys over ALL its window
  * candidates, ignoring the greedy vMatchedDistance filter.  One query per lane, F2 streamed through LDS in
  * 512-keypoint tiles (descriptors + positions + order keys), every LDS read a wave-wide broadcast. */
 #define MK_TILE 512
+#define MK_TOP 8 /* keys kept per query; phase 2 rescans only if fewer than two of them are still allowed */
 __global__ __launch_bounds__(256) void k_match_knn(MatchArgs A) {
     __shared__ uint4 s_d[MK_TILE * 2];
     __shared__ float s_x[MK_TILE], s_y[MK_TILE];
@@ -152,7 +159,9 @@ __global__ __launch_bounds__(256) void k_match_knn(MatchArgs A) {
         a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w;
         a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
     }
-    uint64_t b0 = ~0ull, b1 = ~0ull, b2 = ~0ull, b3 = ~0ull; /* four smallest keys, ascending */
+    uint64_t bk[MK_TOP]; /* the MK_TOP smallest keys, ascending */
+#pragma unroll
+    for (int k = 0; k < MK_TOP; k++) bk[k] = ~0ull;
     for (int t0 = 0; t0 < n2; t0 += MK_TILE) {
         const int nt = min(MK_TILE, n2 - t0);
         __syncthreads();
@@ -172,23 +181,22 @@ __global__ __launch_bounds__(256) void k_match_knn(MatchArgs A) {
                 if (!brute) cand = cand && fabsf(s_x[j] - px) < r && fabsf(s_y[j] - py) < r;
                 const int d = hamming256(a, s_d[2 * j], s_d[2 * j + 1]);
                 const uint64_t key = cand ? (((uint64_t)(uint32_t)d << 32) | ord) : ~0ull;
-                if (key < b3) { /* insert into the sorted quadruple (keys are unique) */
-                    const bool l2 = key < b2, l1 = key < b1, l0 = key < b0;
-                    b3 = l2 ? b2 : key;
-                    b2 = l1 ? b1 : (l2 ? key : b2);
-                    b1 = l0 ? b0 : (l1 ? key : b1);
-                    b0 = l0 ? key : b0;
+                if (key < bk[MK_TOP - 1]) { /* rare once the list has warmed up: sorted insert (keys are unique) */
+#pragma unroll
+                    for (int k = MK_TOP - 1; k > 0; k--) bk[k] = key < bk[k - 1] ? bk[k - 1] : (key < bk[k] ? key : bk[k]);
+                    bk[0] = key < bk[0] ? key : bk[0];
                 }
             }
         }
     }
     if (i1 < n1) {
-        A.knn[((size_t)pair * A.cap + i1) * 2] = make_ulonglong2(b0, b1);
-        A.knn[((size_t)pair * A.cap + i1) * 2 + 1] = make_ulonglong2(b2, b3);
+#pragma unroll
+        for (int k = 0; k < MK_TOP / 2; k++)
+            A.knn[((size_t)pair * A.cap + i1) * (MK_TOP / 2) + k] = make_ulonglong2(bk[2 * k], bk[2 * k + 1]);
     }
 }
 
-/* PHASE 2 (serial resolution) -- one wavefront per frame pair; dynamic LDS: per F2 keypoint {float x,y; u32 ord; i32 m21; u16 mdist} */
+/* PHASE 2 (serial resolution) -- one wavefront per frame pair; dynamic LDS: per F2 keypoint {float x,y; u32 ord; i32 m21; float angle; u16 mdist} */
 __global__ __launch_bounds__(64) void k_match_init(MatchArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int pair = blockIdx.x, lane = threadIdx.x;
@@ -200,10 +208,15 @@ __global__ __launch_bounds__(64) void k_match_init(MatchArgs A) {
     float *s_y = s_x + A.cap;
     uint32_t *s_ord = (uint32_t *)(s_y + A.cap); /* 0xFFFFFFFF = not a candidate for anybody */
     int32_t *s_m21 = (int32_t *)(s_ord + A.cap);
-    uint16_t *s_md = (uint16_t *)(s_m21 + A.cap); /* 0xFFFF = INT_MAX */
+    float *s_ang = (float *)(s_m21 + A.cap);      /* F2 keypoint angles */
+    int32_t *s_m12 = (int32_t *)(s_ang + A.cap);   /* vnMatches12, kept in LDS: no global store inside the serial loop */
+    uint16_t *s_md = (uint16_t *)(s_m12 + A.cap);  /* 0xFFFF = INT_MAX */
+    uint8_t *s_bin = (uint8_t *)(s_md + A.cap);    /* rotation bin of each i1 */
+    uint4 *s_desc = (uint4 *)(smem + (((size_t)A.cap * 27 + 15) & ~(size_t)15)); /* optional: F2 descriptors */
     __shared__ int s_hist[HISTO_LENGTH];
-    int32_t *m12 = A.matches12 + (size_t)pair * A.cap;
-    uint8_t *bins = A.bin_scratch + (size_t)pair * A.cap;
+    int32_t *m12 = s_m12;
+    uint8_t *bins = s_bin;
+    int32_t *m12_out = A.matches12 + (size_t)pair * A.cap;
     const bool brute = A.window < 0;
     const float invW = (float)GRID_COLS / (A.max_x - A.min_x); /* src/Frame.cpp:59-60 */
     const float invH = (float)GRID_ROWS / (A.max_y - A.min_y);
@@ -211,6 +224,7 @@ __global__ __launch_bounds__(64) void k_match_init(MatchArgs A) {
         const OrbKeyPoint kp = k2[j];
         s_x[j] = kp.x;
         s_y[j] = kp.y;
+        s_ang[j] = kp.angle;
         const uint32_t ord = f2_order_key(kp, j, brute, A.min_x, A.min_y, invW, invH);
         s_ord[j] = ord;
         s_m21[j] = -1;
@@ -220,42 +234,60 @@ __global__ __launch_bounds__(64) void k_match_init(MatchArgs A) {
         m12[i] = -1;
         bins[i] = 0xFF;
     }
+    if (A.desc_in_lds)
+        for (int i = lane; i < n2 * 2; i += 64) s_desc[i] = ((const uint4 *)D2)[i];
     if (lane < HISTO_LENGTH) s_hist[lane] = 0;
     __syncthreads();
     const float r = (float)A.window;
     const float factor = HISTO_LENGTH / 360.0f;
-    const ulonglong2 *knn = A.knn + (size_t)pair * A.cap * 2;
+    const ulonglong2 *knn = A.knn + (size_t)pair * A.cap * (MK_TOP / 2);
     for (int base = 0; base < n1; base += 64) {
       /* prefetch the phase-1 result of 64 queries (one per lane), then walk them in order */
-      ulonglong2 m01 = make_ulonglong2(~0ull, ~0ull), m23 = m01;
+      ulonglong2 mk[MK_TOP / 2];
+#pragma unroll
+      for (int k = 0; k < MK_TOP / 2; k++) mk[k] = make_ulonglong2(~0ull, ~0ull);
+      float ang1 = 0.f;
       if (base + lane < n1) {
-          m01 = knn[(size_t)(base + lane) * 2];
-          m23 = knn[(size_t)(base + lane) * 2 + 1];
+#pragma unroll
+          for (int k = 0; k < MK_TOP / 2; k++) mk[k] = knn[(size_t)(base + lane) * (MK_TOP / 2) + k];
+          ang1 = k1[base + lane].angle;
       }
       const int nchunk = min(64, n1 - base);
       for (int t = 0; t < nchunk; t++) {
         const int i1 = base + t;
-        uint64_t c[4];
-        c[0] = __shfl(m01.x, t);
+        /* t is wave-uniform: v_readlane (scalar result) instead of an LDS-crossbar shuffle */
+        uint64_t c[MK_TOP];
+        c[0] = rdlane64(mk[0].x, t);
         if (c[0] == ~0ull) continue; /* no candidate at all (or octave > 0): nothing can match, no state change */
-        c[1] = __shfl(m01.y, t);
-        c[2] = __shfl(m23.x, t);
-        c[3] = __shfl(m23.y, t);
+        c[1] = rdlane64(mk[0].y, t);
+#pragma unroll
+        for (int k = 1; k < MK_TOP / 2; k++) {
+            c[2 * k] = rdlane64(mk[k].x, t);
+            c[2 * k + 1] = rdlane64(mk[k].y, t);
+        }
+        const float angle1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ang1), t));
         /* the filtered candidate set (:49-50) is a subset of the unfiltered one, so its two smallest keys are
-           the first two ALLOWED entries of the sorted unfiltered list -- if they show up within the top 4 */
+           the first two ALLOWED entries of the sorted unfiltered list -- if they show up within the top MK_TOP.
+           The vMatchedDistance look-ups are independent LDS reads (issued together). */
+        int mdv[MK_TOP];
+#pragma unroll
+        for (int k = 0; k < MK_TOP; k++) {
+            const int jk = (c[k] == ~0ull) ? 0 : (int)(c[k] & 0xFFFFu);
+            const uint16_t raw = s_md[jk];
+            mdv[k] = raw == 0xFFFF ? 0x7FFFFFFF : (int)raw;
+        }
         uint64_t gKey = ~0ull;
         int bestDist2 = 0x7FFFFFFF;
         int found = 0;
-        bool complete = false; /* the top-4 list is the whole candidate set */
+        bool complete = false; /* the list is the whole candidate set */
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < MK_TOP; k++) {
             if (c[k] == ~0ull) {
                 complete = true;
                 break;
             }
-            const int jk = (int)(c[k] & 0xFFFFu), dk = (int)(c[k] >> 32);
-            const int mdk = s_md[jk] == 0xFFFF ? 0x7FFFFFFF : (int)s_md[jk];
-            if (!(mdk <= dk)) {
+            const int dk = (int)(c[k] >> 32);
+            if (!(mdv[k] <= dk)) {
                 if (found == 0)
                     gKey = c[k];
                 else if (found == 1)
@@ -290,7 +322,7 @@ __global__ __launch_bounds__(64) void k_match_init(MatchArgs A) {
                 cand = fabsf(dx) < r && fabsf(dy) < r;
             }
             if (cand) {
-                const uint4 *p = (const uint4 *)(D2 + (size_t)j * 32);
+                const uint4 *p = A.desc_in_lds ? (s_desc + 2 * j) : (const uint4 *)(D2 + (size_t)j * 32);
                 const int d = hamming256(a, p[0], p[1]);
                 const int md = s_md[j] == 0xFFFF ? 0x7FFFFFFF : (int)s_md[j];
                 if (!(md <= d)) { /* :49-50 */
@@ -318,7 +350,7 @@ __global__ __launch_bounds__(64) void k_match_init(MatchArgs A) {
                     s_m21[bestIdx2] = i1;
                     s_md[bestIdx2] = (uint16_t)bestDist;
                     if (A.check_ori) {
-                        float rot = k1[i1].angle - k2[bestIdx2].angle;
+                        float rot = angle1 - s_ang[bestIdx2];
                         if (rot < 0.0f) rot += 360.0f;
                         int bin = (int)roundf(rot * factor);
                         if (bin == HISTO_LENGTH) bin = 0;
@@ -365,6 +397,7 @@ __global__ __launch_bounds__(64) void k_match_init(MatchArgs A) {
     int cnt = 0;
     for (int i = lane; i < n1; i += 64) {
         const int m = m12[i];
+        m12_out[i] = m;
         if (m >= 0) {
             cnt++;
             if (A.prev_out) {
@@ -430,7 +463,7 @@ extern "C" int orb_matcher_create(int max_keypoints, int max_pairs, int device_i
         hipMalloc((void **)&m->d_m12, (size_t)max_pairs * K * 4) != hipSuccess ||
         hipMalloc((void **)&m->d_nm, (size_t)max_pairs * 4) != hipSuccess ||
         hipMalloc((void **)&m->d_bins, (size_t)max_pairs * K) != hipSuccess ||
-        hipMalloc((void **)&m->d_knn, (size_t)max_pairs * K * 2 * sizeof(ulonglong2)) != hipSuccess ||
+        hipMalloc((void **)&m->d_knn, (size_t)max_pairs * K * (MK_TOP / 2) * sizeof(ulonglong2)) != hipSuccess ||
         hipMalloc((void **)&m->d_idx, K * 4) != hipSuccess || hipMalloc((void **)&m->d_best, K * 2) != hipSuccess ||
         hipMalloc((void **)&m->d_second, K * 2) != hipSuccess) {
         orb_matcher_destroy(m);
@@ -557,10 +590,13 @@ extern "C" int orb_hamming_knn2(OrbMatcher *m, const uint8_t *d1, int n1, const 
     return ORB_OK;
 }
 
-static size_t match_lds_bytes(int cap) { return (size_t)cap * (4 + 4 + 4 + 4 + 2) + 64; }
+static size_t match_lds_bytes(int cap) { return (((size_t)cap * 27 + 15) & ~(size_t)15) + 64; }
 
-static int launch_match(const MatchArgs &A, int n_pairs, hipStream_t st) {
-    const size_t lds = match_lds_bytes(A.cap);
+static int launch_match(const MatchArgs &A_in, int n_pairs, hipStream_t st) {
+    MatchArgs A = A_in;
+    size_t lds = match_lds_bytes(A.cap);
+    A.desc_in_lds = (lds + (size_t)A.cap * 32 <= 96 * 1024) ? 1 : 0; /* keeps >= 1 workgroup per CU resident */
+    if (A.desc_in_lds) lds += (size_t)A.cap * 32;
     if (lds > 160 * 1024 - 1024) {
         m_err = "matcher: keypoint capacity too large for the LDS-resident frame state";
         return ORB_E_CAPACITY;
