@@ -26,10 +26,12 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/orbslam_amd.h"
@@ -403,18 +405,40 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
             }
         }
         __syncthreads();
-        /* ---- S = Hpp + lambda I - sum Y W^T : one wavefront per non-zero block, lanes = 6x6 entries ---- */
+        /* ---- S = Hpp + lambda I - sum Y W^T : one wavefront per non-zero 6x6 block.  Each LANE takes whole
+           contributions (stride 64: 64 independent Y/W gathers in flight), accumulates its own 6x6 partial in
+           registers, and the 36 partials are summed across the wavefront with shuffles -- fixed order, no
+           atomics. ---- */
         for (int bk = wave; bk < w.nnzb; bk += BA_W) {
             const int k0 = I[w.con_start + bk], k1 = I[w.con_start + bk + 1];
-            const int r = lane / 6, c = lane % 6;
-            double acc = 0;
-            if (lane < 36) {
-                for (int k = k0; k < k1; k++) {
-                    const double *Y1 = D + w.Y + (int64_t)I[w.con_e1 + k] * 18 + r * 3;
-                    const double *W2 = D + w.W + (int64_t)I[w.con_e2 + k] * 18 + c * 3;
-                    acc += Y1[0] * W2[0] + Y1[1] * W2[1] + Y1[2] * W2[2];
+            double acc[36];
+#pragma unroll
+            for (int i = 0; i < 36; i++) acc[i] = 0.0;
+            for (int k = k0 + lane; k < k1; k += 64) {
+                const double *Y1 = D + w.Y + (int64_t)I[w.con_e1 + k] * 18;
+                const double *W2 = D + w.W + (int64_t)I[w.con_e2 + k] * 18;
+                double y[18], ww[18];
+#pragma unroll
+                for (int i = 0; i < 18; i++) {
+                    y[i] = Y1[i];
+                    ww[i] = W2[i];
                 }
-                D[w.S + (int64_t)bk * 36 + lane] = -acc;
+#pragma unroll
+                for (int r = 0; r < 6; r++)
+#pragma unroll
+                    for (int c = 0; c < 6; c++)
+                        acc[r * 6 + c] += y[r * 3] * ww[c * 3] + y[r * 3 + 1] * ww[c * 3 + 1] + y[r * 3 + 2] * ww[c * 3 + 2];
+            }
+#pragma unroll
+            for (int i = 0; i < 36; i++) {
+                double v = acc[i];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                acc[i] = v;
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 36; i++) D[w.S + (int64_t)bk * 36 + i] = -acc[i];
             }
         }
         __syncthreads();
@@ -518,10 +542,12 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
                         const int sl = i / 6, a = i % 6;
                         const int b0 = I[w.blk_row + sl], b1 = I[w.blk_row + sl + 1];
                         double v = 0;
+#pragma unroll 4
                         for (int bk = b0; bk < b1; bk++) {
-                            const double *Sr = D + w.S + (int64_t)bk * 36 + a * 6;
+                            const double2 *Sr = (const double2 *)(D + w.S + (int64_t)bk * 36 + a * 6); /* 16-B aligned */
                             const double *pv = s.vp + I[w.blk_col + bk] * 6;
-                            v += Sr[0] * pv[0] + Sr[1] * pv[1] + Sr[2] * pv[2] + Sr[3] * pv[3] + Sr[4] * pv[4] + Sr[5] * pv[5];
+                            const double2 s0 = Sr[0], s1 = Sr[1], s2 = Sr[2];
+                            v += s0.x * pv[0] + s0.y * pv[1] + s1.x * pv[2] + s1.y * pv[3] + s2.x * pv[4] + s2.y * pv[5];
                         }
                         Ap[q] = v;
                         pAp_loc += pi[q] * v;
@@ -742,6 +768,10 @@ struct HostWin {
 };
 /* fields of BAWin that are device-only scratch: their offsets are relative to the scratch base until
  * ba_solve_batch adds the size of the staged (uploaded) region */
+static int64_t BAWin::*const kInputDFields[] = {&BAWin::poses, &BAWin::pts, &BAWin::obs, &BAWin::info, &BAWin::st};
+static int64_t BAWin::*const kIntFields[] = {&BAWin::cam,     &BAWin::pt,      &BAWin::pt_start, &BAWin::cam_start,
+                                             &BAWin::cam_edges, &BAWin::slot,  &BAWin::blk_row,  &BAWin::blk_col,
+                                             &BAWin::blk_diag, &BAWin::con_start, &BAWin::con_e1, &BAWin::con_e2};
 static int64_t BAWin::*const kScratchFields[] = {&BAWin::poses_t, &BAWin::pts_t, &BAWin::err, &BAWin::err_t, &BAWin::W,
                                                  &BAWin::Y,       &BAWin::Hpp,   &BAWin::bp,  &BAWin::Hll,   &BAWin::bl,
                                                  &BAWin::Dinv,    &BAWin::S,     &BAWin::g,   &BAWin::Minv,  &BAWin::x,
@@ -953,16 +983,61 @@ extern "C" int ba_solve_batch(BASolver *s, const BAProblem *probs, BAResult *res
     std::vector<double> hD;
     std::vector<int32_t> hI;
     std::vector<uint8_t> hB;
+    const bool prof = getenv("ORBSLAM_AMD_BA_PROFILE") != nullptr;
+    auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = tnow();
     std::vector<HostWin> hw(nwin);
     std::vector<BAWin> wins(nwin);
     size_t scratchD = 0;
-    for (int i = 0; i < nwin; i++) {
-        int rc = stage_problem(&probs[i], hD, scratchD, hI, hB, hw[i]);
-        if (rc) return rc;
-    }
-    for (int i = 0; i < nwin; i++) {
-        for (auto f : kScratchFields) hw[i].w.*f += (int64_t)hD.size();
-        wins[i] = hw[i].w;
+    {
+        /* every window is staged into its own vectors on a pool of host threads (index sorting and the
+           contribution lists are O(sum k^2) per window), then the pieces are concatenated */
+        struct Piece {
+            std::vector<double> D;
+            std::vector<int32_t> I;
+            std::vector<uint8_t> B;
+            size_t scratch = 0;
+            int rc = 0;
+        };
+        std::vector<Piece> pieces(nwin);
+        const int nthr = std::max(1, std::min<int>(nwin, std::min<int>(16, (int)std::thread::hardware_concurrency())));
+        auto work = [&](int t) {
+            for (int i = t; i < nwin; i += nthr)
+                pieces[i].rc = stage_problem(&probs[i], pieces[i].D, pieces[i].scratch, pieces[i].I, pieces[i].B, hw[i]);
+        };
+        if (nthr == 1)
+            work(0);
+        else {
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nthr; t++) pool.emplace_back(work, t);
+            for (auto &th : pool) th.join();
+        }
+        size_t nD = 0, nI = 0, nB = 0;
+        for (int i = 0; i < nwin; i++) {
+            if (pieces[i].rc) return pieces[i].rc;
+            nD += pieces[i].D.size();
+            nI += pieces[i].I.size();
+            nB += pieces[i].B.size();
+        }
+        hD.resize(nD);
+        hI.resize(nI);
+        hB.resize(nB);
+        size_t oD = 0, oI = 0, oB = 0;
+        for (int i = 0; i < nwin; i++) {
+            Piece &pc = pieces[i];
+            std::copy(pc.D.begin(), pc.D.end(), hD.begin() + oD);
+            std::copy(pc.I.begin(), pc.I.end(), hI.begin() + oI);
+            std::copy(pc.B.begin(), pc.B.end(), hB.begin() + oB);
+            for (auto f : kInputDFields) hw[i].w.*f += (int64_t)oD;
+            for (auto f : kIntFields) hw[i].w.*f += (int64_t)oI;
+            hw[i].w.flags += (int64_t)oB;
+            for (auto f : kScratchFields) hw[i].w.*f += (int64_t)(nD + scratchD);
+            scratchD += pc.scratch;
+            oD += pc.D.size();
+            oI += pc.I.size();
+            oB += pc.B.size();
+            wins[i] = hw[i].w;
+        }
     }
     int rc;
     if ((rc = ba_grow(s->dD, s->capD, hD.size() + scratchD))) return rc;
@@ -974,6 +1049,8 @@ extern "C" int ba_solve_batch(BASolver *s, const BAProblem *probs, BAResult *res
     if (!hB.empty()) BCHK(hipMemcpyAsync(s->dB, hB.data(), hB.size(), hipMemcpyHostToDevice, s->stream));
     BCHK(hipMemcpyAsync(s->dW, wins.data(), (size_t)nwin * sizeof(BAWin), hipMemcpyHostToDevice, s->stream));
     BABufs bufs{s->dD, s->dI, s->dB, s->dW};
+    if (prof) BCHK(hipStreamSynchronize(s->stream));
+    const double t_staged = tnow();
     auto stopped = [&]() {
         for (int i = 0; i < nwin; i++)
             if (probs[i].stop && *probs[i].stop) return true;
@@ -981,7 +1058,8 @@ extern "C" int ba_solve_batch(BASolver *s, const BAProblem *probs, BAResult *res
     };
     int maxn = 0;
     for (int i = 0; i < nwin; i++) maxn = std::max(maxn, wins[i].Ncf * 6);
-    const int pcg_maxit = 6 * maxn + 100; /* CG needs > n steps in floating point when S is ill-conditioned */
+    int pcg_maxit = 6 * maxn + 100; /* CG needs > n steps in floating point when S is ill-conditioned */
+    if (getenv("ORBSLAM_AMD_PCG_MAXIT")) pcg_maxit = atoi(getenv("ORBSLAM_AMD_PCG_MAXIT")); /* profiling only */
     bool halted = false;
     for (int round = 0; round < P0.n_rounds && !halted; round++) {
         for (int it = 0; it < P0.rounds[round]; it++) {
@@ -1007,6 +1085,8 @@ extern "C" int ba_solve_batch(BASolver *s, const BAProblem *probs, BAResult *res
     }
     hipLaunchKernelGGL(k_ba_classify, dim3(nwin), dim3(BA_T), 0, s->stream, bufs, 0, 1);
     BCHK(hipGetLastError());
+    if (prof) BCHK(hipStreamSynchronize(s->stream));
+    const double t_solved = tnow();
     /* results */
     for (int i = 0; i < nwin; i++) { /* only poses, points and the LM state come back */
         const BAWin &w = wins[i];
@@ -1026,6 +1106,13 @@ extern "C" int ba_solve_batch(BASolver *s, const BAProblem *probs, BAResult *res
         res[i].chi2_final = hD[w.st + ST_CHI];
         res[i].iterations = (int)hD[w.st + ST_ITERS];
         res[i].lin_solves = (int)hD[w.st + ST_SOLVES];
+    }
+    if (prof) {
+        double pcg = 0;
+        for (int i = 0; i < nwin; i++) pcg += hD[wins[i].st + ST_PCG_ITERS];
+        fprintf(stderr, "[ba] %d windows: stage+upload %.2f ms, device %.2f ms, download %.2f ms, D %.1f MB, I %.1f MB, pcg its/window %.0f\n",
+                nwin, (t_staged - t_start) * 1e3, (t_solved - t_staged) * 1e3, (tnow() - t_solved) * 1e3,
+                (hD.size() + scratchD) * 8e-6, hI.size() * 4e-6, pcg / nwin);
     }
     return ORB_OK;
 }
