@@ -66,6 +66,26 @@ def cpu_baseline(n_frames):
                       % (n_frames, dt)}
 
 
+def ba_throughput(device, n_windows):
+    """second half of BASELINE.json's metric: local-BA windows/s at the north_star target size
+    (100 KFs x 5000 points, 5+10 LM iterations), a batch of independent windows on this GPU"""
+    import orbslam_in_practice_amd as oa
+    from orbslam_in_practice_amd import synth
+    uniq = [synth.make_ba_window(900 + i, 100, 5000) for i in range(4)]
+    wins = [uniq[i % 4] for i in range(n_windows)]
+    E = max(len(w["obs"]) for w in uniq)
+    opt = oa.Optimizer(max_cams=100, max_points=5000, max_obs=E, max_batch=n_windows, device=device)
+    opt.solve_batch(wins[:2], (5, 10))
+    t0 = time.perf_counter()
+    res = opt.solve_batch(wins, (5, 10))
+    dt = time.perf_counter() - t0
+    opt.close()
+    return {"value": round(n_windows / dt, 2), "unit": "windows/s", "dtype": "f64",
+            "workload": "local BA, %d windows of 100 KFs x 5000 points (E~%d), 5+10 LM iterations, host staging "
+                        "included" % (n_windows, E),
+            "chi2_ratio": round(float(np.mean([r["chi2_final"] / r["chi2_initial"] for r in res])), 5)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,6 +93,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--cpu-frames", type=int, default=48, help="CPU baseline sample size (0 = skip)")
+    ap.add_argument("--ba-windows", type=int, default=64, help="windows in the local-BA side measurement (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -193,6 +214,8 @@ def main():
         }
         if world == 1 and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_frames)
+        if world == 1 and args.ba_windows > 0:
+            out["local_ba"] = ba_throughput(local_rank, args.ba_windows)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

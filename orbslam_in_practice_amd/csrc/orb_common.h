@@ -84,6 +84,15 @@ __host__ __device__ inline uint8_t *level_ptr(uint8_t *base, const OrbGeom &g, i
     return base + (int64_t)frame * g.pyr_frame_bytes + g.lv[level].plane_off;
 }
 
+/* XCD-aware work-item order (MI355X: 8 XCDs, each with its own L2; workgroups are dealt round-robin, so ids
+ * b and b+8 share an L2).  Maps the hardware's linear workgroup id to a work-item index such that
+ * CONSECUTIVE work items (x-adjacent cells / tiles, which share 128-B lines) land on the SAME XCD at about
+ * the same time.  Bijective for any nwg (guide: cdna_hip_programming.md T1).  Speed only, never correctness. */
+__device__ __forceinline__ int xcd_remap(int lin, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = lin & 7, slot = lin >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
 /* launchers (one per kernel family); all enqueue on `st` and return hipGetLastError() */
 hipError_t launch_pyramid(const OrbGeom &g, const OrbBuffers &b, const uint8_t *d_imgs, int stride,
                           int64_t frame_stride, int n_frames, hipStream_t st);

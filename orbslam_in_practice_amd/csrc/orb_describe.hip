@@ -79,9 +79,12 @@ __device__ __forceinline__ void sincos_det(float angle, float *c_out, float *s_o
 __global__ __launch_bounds__(256) void k_describe(OrbGeom g, const uint8_t *pyr, const uint8_t *blur,
                                                    const uint32_t *lvl_kp, const int32_t *lvl_cnt, OrbKeyPoint *kps,
                                                    uint8_t *desc, int cap, int32_t *counts) {
-    const int frame = blockIdx.y;
+    /* all keypoints of one frame run on ONE XCD (consecutive remapped items share an L2): the frame's pyramid and
+       blurred pyramid (2 MB) then stay L2-resident while its ~1000 patches are gathered from them */
+    const int item = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int frame = item / (int)gridDim.x, bx = item - frame * (int)gridDim.x;
     const int lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6); /* slot in the frame's level-kp array */
+    const int slot = bx * 4 + (threadIdx.x >> 6); /* slot in the frame's level-kp array */
     const int32_t *lc = lvl_cnt + (int64_t)frame * g.nlevels;
     int level = 0, before = 0;
     while (level + 1 < g.nlevels && slot >= g.lv[level + 1].out_base) {

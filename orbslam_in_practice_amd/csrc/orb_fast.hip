@@ -73,7 +73,8 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells(OrbGeom g, const uint8_t 
     __shared__ __attribute__((aligned(16))) uint8_t s_sc[ORB_CELL_MAX][FT_LD];
     __shared__ int s_wave[4];
     __shared__ int s_any;
-    const int cell = blockIdx.x, frame = blockIdx.y;
+    const int item = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int frame = item / g.total_cells, cell = item - frame * g.total_cells;
     const CellDesc cd = cells[cell];
     const LevelGeom &L = g.lv[cd.level];
     const int rw = cd.rw, rh = cd.rh;

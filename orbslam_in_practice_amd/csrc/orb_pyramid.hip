@@ -98,12 +98,13 @@ __device__ __forceinline__ int reflect101(int p, int n) {
 __global__ __launch_bounds__(256) void k_blur(OrbGeom g, const uint8_t *pyr, uint8_t *blur, TileMap tm) {
     __shared__ __attribute__((aligned(16))) uint8_t s_in[BL_TH + 6][BL_TW + 8];   /* column c <-> x = tx0 - 4 + c */
     __shared__ __attribute__((aligned(16))) uint16_t s_h[BL_TH + 6][BL_TW];
+    const int item = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int frame = item / (int)gridDim.x, bx = item - frame * (int)gridDim.x;
     int level = 0;
-    while (level + 1 < g.nlevels && (int)blockIdx.x >= tm.prefix[level + 1]) level++;
+    while (level + 1 < g.nlevels && bx >= tm.prefix[level + 1]) level++;
     const LevelGeom &L = g.lv[level];
-    const int t = blockIdx.x - tm.prefix[level];
+    const int t = bx - tm.prefix[level];
     const int tx0 = (t % tm.tiles_x[level]) * BL_TW, ty0 = (t / tm.tiles_x[level]) * BL_TH;
-    const int frame = blockIdx.y;
     const uint8_t *src = level_ptr(pyr, g, frame, level);
     uint8_t *dst = level_ptr(blur, g, frame, level);
     const int tid = threadIdx.x;

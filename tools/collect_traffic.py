@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs as MI355X_MICROARCH.md prescribes:
+they do not fit one TCC pass) into profiles/traffic.json: HBM-side bytes per LAUNCH for every stage of the
+front-end, which bench.py copies into roofline.traffic for the dominant stage.
+
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py ...
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py ...
+    python tools/collect_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/traffic.json <batch>
+
+Units/corrections (MI355X_MICROARCH.md, HBM section): the counters are in KiB; on gfx950 FETCH_SIZE reports
+exactly HALF of the bytes of a wide coalesced streaming read (TCC_EA0_RDREQ tallies 128-B requests at 64 B),
+so the read side is doubled; WRITE_SIZE is exact for streaming stores.  Byte-granular gathers (FAST staging,
+describe) are outside the guide's calibrated patterns: their corrected figure is an upper bound.
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+STAGE = {"k_copy_level0": "pyramid", "k_resize": "pyramid", "k_fast_cells": "fast", "k_quadtree": "quadtree",
+         "k_blur": "blur", "k_describe": "describe", "k_match_knn": "match", "k_match_init": "match"}
+LAUNCHES_PER_STEP = {"pyramid": 1, "fast": 1, "quadtree": 1, "blur": 1, "describe": 1, "match": 1}
+
+
+def load(d, counter):
+    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    tot = collections.defaultdict(float)
+    calls = collections.Counter()
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+        if name in STAGE:
+            tot[STAGE[name]] += float(r["Counter_Value"])
+            if name in ("k_copy_level0", "k_fast_cells", "k_quadtree", "k_blur", "k_describe", "k_match_init"):
+                calls[STAGE[name]] += 1
+    return tot, calls
+
+
+def main():
+    fetch_dir, write_dir, out, batch = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+    fetch, calls = load(fetch_dir, "FETCH_SIZE")
+    write, calls_w = load(write_dir, "WRITE_SIZE")
+    res = {"_note": "HBM-side bytes per launch (one launch = one batch of %d frames); fetch doubled per the gfx950 "
+                    "FETCH_SIZE correction, write as counted" % batch, "_batch": batch}
+    for st in LAUNCHES_PER_STEP:
+        if calls[st] == 0:
+            continue
+        f = fetch[st] / calls[st] * 1024.0 * 2.0
+        w = write[st] / max(calls_w[st], 1) * 1024.0
+        res[st] = int(f + w)
+        res["_" + st + "_fetch_raw_kib"] = round(fetch[st] / calls[st], 1)
+        res["_" + st + "_write_kib"] = round(write[st] / max(calls_w[st], 1), 1)
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
