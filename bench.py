@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=512, help="frames per GPU per step")
     ap.add_argument("--cpu-frames", type=int, default=48, help="CPU baseline sample size (0 = skip)")
     ap.add_argument("--ba-windows", type=int, default=64, help="windows in the local-BA side measurement (0 = skip)")
     args = ap.parse_args()
@@ -106,11 +106,26 @@ def main():
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product has no CPU fallback)")
+    # REHEARSAL ONLY (one-GPU box): BENCH_REHEARSE=1 puts every rank on cuda:0 and swaps RCCL for gloo, to
+    # exercise the multi-rank control flow; numbers from such a run are meaningless and say so.
+    rehearse = os.environ.get("BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+
+    def all_gather_flat(out, inp):
+        if rehearse:  # gloo: list form
+            parts = list(out.view(world, -1).unbind(0))
+            dist.all_gather(parts, inp.view(-1))
+        else:
+            dist.all_gather_into_tensor(out.view(-1), inp.view(-1))
 
     import orbslam_in_practice_amd as oa
     from orbslam_in_practice_amd import synth
@@ -128,10 +143,16 @@ def main():
     d_desc = torch.zeros((nG, cap, 32), dtype=torch.uint8, device=dev)
     d_cnt = torch.zeros((nG,), dtype=torch.int32, device=dev)
     lo = rank * B
-    k_loc, d_loc, c_loc = d_kps[lo:lo + B], d_desc[lo:lo + B], d_cnt[lo:lo + B]
-    pa = torch.arange(lo, lo + B, dtype=torch.int32, device=dev)
-    pb = torch.remainder(pa + 1, nG).to(torch.int32) if world > 1 else \
-        torch.remainder(torch.arange(1, B + 1, dtype=torch.int32, device=dev), B).to(torch.int32)
+    if world > 1:  # separate send buffers: the all-gather never aliases its own output
+        k_loc = torch.zeros((B, cap, 28), dtype=torch.uint8, device=dev)
+        d_loc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+        c_loc = torch.zeros((B,), dtype=torch.int32, device=dev)
+    else:
+        k_loc, d_loc, c_loc = d_kps, d_desc, d_cnt
+    from orbslam_in_practice_amd import shard
+    pa_h, pb_h = shard.stream_pairs(rank, world, B)  # (k, k+1) in the global stream; the last one wraps
+    pa = torch.from_numpy(pa_h).to(dev)
+    pb = torch.from_numpy(pb_h).to(dev)
     d_m12 = torch.full((B, cap), -1, dtype=torch.int32, device=dev)
     d_nm = torch.zeros((B,), dtype=torch.int32, device=dev)
     bounds = (0.0, float(W), 0.0, float(H))
@@ -143,9 +164,9 @@ def main():
         ext.extract_batch_device(d_imgs.data_ptr(), B, W, H, W, W * H, k_loc.data_ptr(), d_loc.data_ptr(), cap,
                                  c_loc.data_ptr(), sp)
         if world > 1:  # the one exchange step of the path: fixed-capacity feature slabs over xGMI
-            dist.all_gather_into_tensor(d_kps.view(-1), k_loc.reshape(-1))
-            dist.all_gather_into_tensor(d_desc.view(-1), d_loc.reshape(-1))
-            dist.all_gather_into_tensor(d_cnt, c_loc)
+            all_gather_flat(d_kps, k_loc)
+            all_gather_flat(d_desc, d_loc)
+            all_gather_flat(d_cnt, c_loc)
         matcher.match_batch_device(d_kps.data_ptr(), d_desc.data_ptr(), d_cnt.data_ptr(), cap, pa.data_ptr(),
                                    pb.data_ptr(), B, bounds, -1, d_m12.data_ptr(), d_nm.data_ptr(), sp)
 
@@ -201,6 +222,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "rehearsal": rehearse,
             "config": {"workload": "configs[1]: ORB extract (8 levels, 1000 features, FAST 20/7) + brute-force "
                                    "Hamming match of consecutive frames, 640x480 stream",
                        "frames_per_gpu_per_step": B, "pairs_per_gpu_per_step": B,
