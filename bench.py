@@ -214,7 +214,9 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom)
+                tj = json.load(open(tpath))
+                if dom in tj:  # collected per launch at tj['_batch'] frames; per-frame traffic is batch independent
+                    traffic = int(tj[dom] * B / float(tj.get("_batch", B)))
             except Exception:
                 traffic = None
         out = {

@@ -54,7 +54,8 @@ typedef struct OrbConfig {
 typedef struct OrbExtractor OrbExtractor; /* opaque */
 
 /* ---- ORBextractor (replaces reference src/ORBextractor.cpp:360-420 ctor) ----------------------
- * max_w/max_h/max_batch size the device buffers (any smaller frame / batch is accepted later). */
+ * max_w/max_h/max_batch size the device buffers; a larger frame grows them on first use, a larger batch
+ * is refused with ORB_E_CAPACITY. */
 int orb_create(const OrbConfig *cfg, int max_w, int max_h, int max_batch, int device_id, OrbExtractor **out);
 void orb_destroy(OrbExtractor *h);
 

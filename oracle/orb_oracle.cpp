@@ -227,6 +227,16 @@ int fast_corner_score(const uint8_t *ptr, int stride, int threshold) {
 /* is the pixel a 9/16 corner at `threshold` (>= 9 contiguous ring pixels all > v+t or all < v-t) */
 inline bool fast_is_corner(const uint8_t *ptr, int stride, int threshold) {
     int v = ptr[0];
+    { /* the usual high-speed rejection (OpenCV's FAST does the same through its threshold table): every 9-arc
+         holds two adjacent compass pixels, so without such a pair on one side there is no corner */
+        const int hi = v + threshold, lo = v - threshold;
+        const int p0 = ptr[3 * stride], p4 = ptr[3], p8 = ptr[-3 * stride], p12 = ptr[-3];
+        const bool b0 = p0 > hi, b4 = p4 > hi, b8 = p8 > hi, b12 = p12 > hi;
+        const bool d0 = p0 < lo, d4 = p4 < lo, d8 = p8 < lo, d12 = p12 < lo;
+        if (!((b0 && b4) || (b4 && b8) || (b8 && b12) || (b12 && b0) || (d0 && d4) || (d4 && d8) || (d8 && d12) ||
+              (d12 && d0)))
+            return false;
+    }
     int ring[25];
     for (int k = 0; k < 16; k++) ring[k] = ptr[fast_off16[k][1] * stride + fast_off16[k][0]];
     for (int k = 16; k < 25; k++) ring[k] = ring[k - 16];
@@ -255,8 +265,9 @@ void fast9_16(const uint8_t *roi, int w, int h, int stride, int threshold, bool 
               std::vector<OrcKeyPoint> &out) {
     out.clear();
     if (w < 7 || h < 7) return;
-    std::vector<uint8_t> score((size_t)w * h, 0);
-    std::vector<uint8_t> is_c((size_t)w * h, 0);
+    static thread_local std::vector<uint8_t> score, is_c;
+    score.assign((size_t)w * h, 0);
+    is_c.assign((size_t)w * h, 0);
     for (int y = 3; y < h - 3; y++)
         for (int x = 3; x < w - 3; x++) {
             const uint8_t *p = roi + (size_t)y * stride + x;

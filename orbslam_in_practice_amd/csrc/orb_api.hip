@@ -321,6 +321,45 @@ static int set_geometry(OrbExtractor *h, int w, int hgt) {
     return ORB_OK;
 }
 
+static void free_staging(OrbExtractor *h) {
+    (void)hipFree(h->d_in);
+    (void)hipFree(h->d_kps);
+    (void)hipFree(h->d_desc);
+    (void)hipFree(h->d_counts);
+    if (h->h_in) (void)hipHostFree(h->h_in);
+    if (h->h_kps) (void)hipHostFree(h->h_kps);
+    if (h->h_desc) (void)hipHostFree(h->h_desc);
+    if (h->h_counts) (void)hipHostFree(h->h_counts);
+    h->d_in = h->h_in = nullptr;
+    h->d_kps = h->h_kps = nullptr;
+    h->d_desc = h->h_desc = nullptr;
+    h->d_counts = h->h_counts = nullptr;
+}
+
+extern "C" int orb_max_keypoints(const OrbExtractor *h);
+
+/* pinned + device staging of the host-pointer API, sized for batch frames of w x hgt */
+static int alloc_staging(OrbExtractor *h, int w, int hgt, int batch) {
+    free_staging(h);
+    h->out_cap = orb_max_keypoints(h);
+    const size_t in_bytes = (size_t)batch * align_up(w, 64) * hgt;
+    h->cap_in = in_bytes;
+    if (hipMalloc((void **)&h->d_in, in_bytes) != hipSuccess || hipHostMalloc((void **)&h->h_in, in_bytes) != hipSuccess ||
+        hipMalloc((void **)&h->d_kps, (size_t)batch * h->out_cap * sizeof(OrbKeyPoint)) != hipSuccess ||
+        hipHostMalloc((void **)&h->h_kps, (size_t)batch * h->out_cap * sizeof(OrbKeyPoint)) != hipSuccess ||
+        hipMalloc((void **)&h->d_desc, (size_t)batch * h->out_cap * 32) != hipSuccess ||
+        hipHostMalloc((void **)&h->h_desc, (size_t)batch * h->out_cap * 32) != hipSuccess ||
+        hipMalloc((void **)&h->d_counts, (size_t)batch * 4) != hipSuccess ||
+        hipHostMalloc((void **)&h->h_counts, (size_t)batch * 4) != hipSuccess) {
+        g_err = "staging allocation failed";
+        return ORB_E_HIP;
+    }
+    h->max_w = w;
+    h->max_h = hgt;
+    h->max_batch = batch;
+    return ORB_OK;
+}
+
 extern "C" int orb_max_keypoints(const OrbExtractor *h) {
     if (!h) return 0;
     /* the quadtree stops at >= quota nodes and can overshoot by at most 3 per level */
@@ -369,20 +408,7 @@ extern "C" int orb_create(const OrbConfig *cfg, int max_w, int max_h, int max_ba
     }
     if ((rc = set_geometry(h, max_w, max_h))) return fail(rc);
     if ((rc = ensure_buffers(h, max_batch))) return fail(rc);
-    /* staging */
-    h->out_cap = orb_max_keypoints(h);
-    const size_t in_bytes = (size_t)max_batch * h->geom.lv[0].pitch * max_h;
-    h->cap_in = in_bytes;
-    if (hipMalloc((void **)&h->d_in, in_bytes) != hipSuccess || hipHostMalloc((void **)&h->h_in, in_bytes) != hipSuccess ||
-        hipMalloc((void **)&h->d_kps, (size_t)max_batch * h->out_cap * sizeof(OrbKeyPoint)) != hipSuccess ||
-        hipHostMalloc((void **)&h->h_kps, (size_t)max_batch * h->out_cap * sizeof(OrbKeyPoint)) != hipSuccess ||
-        hipMalloc((void **)&h->d_desc, (size_t)max_batch * h->out_cap * 32) != hipSuccess ||
-        hipHostMalloc((void **)&h->h_desc, (size_t)max_batch * h->out_cap * 32) != hipSuccess ||
-        hipMalloc((void **)&h->d_counts, (size_t)max_batch * 4) != hipSuccess ||
-        hipHostMalloc((void **)&h->h_counts, (size_t)max_batch * 4) != hipSuccess) {
-        g_err = "orb_create: staging allocation failed";
-        return fail(ORB_E_HIP);
-    }
+    if ((rc = alloc_staging(h, max_w, max_h, max_batch))) return fail(rc);
     *out = h;
     return ORB_OK;
 }
@@ -403,14 +429,7 @@ extern "C" void orb_destroy(OrbExtractor *h) {
     (void)hipFree(h->d_cells);
     (void)hipFree(h->d_tab_i);
     (void)hipFree(h->d_tab_c);
-    (void)hipFree(h->d_in);
-    (void)hipFree(h->d_kps);
-    (void)hipFree(h->d_desc);
-    (void)hipFree(h->d_counts);
-    if (h->h_in) (void)hipHostFree(h->h_in);
-    if (h->h_kps) (void)hipHostFree(h->h_kps);
-    if (h->h_desc) (void)hipHostFree(h->h_desc);
-    if (h->h_counts) (void)hipHostFree(h->h_counts);
+    free_staging(h);
     for (int r = 0; r < OrbExtractor::kProfRing; r++)
         for (int i = 0; i < 6; i++)
             if (h->ev[r][i]) (void)hipEventDestroy(h->ev[r][i]);
@@ -526,12 +545,16 @@ extern "C" int orb_extract_batch(OrbExtractor *h, const uint8_t *const *imgs, in
         g_err = "orb_extract_batch: bad argument";
         return ORB_E_INVALID;
     }
-    if (n_frames > h->max_batch || w > h->max_w || hgt > h->max_h) {
-        g_err = "orb_extract_batch: frame or batch larger than the handle was created for";
+    if (n_frames > h->max_batch) {
+        g_err = "orb_extract_batch: batch larger than the handle was created for";
         return ORB_E_CAPACITY;
     }
     HIPCHK(hipSetDevice(h->device));
     int rc;
+    if (w > h->max_w || hgt > h->max_h) { /* a larger frame than announced: grow the staging once */
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if ((rc = alloc_staging(h, std::max(w, h->max_w), std::max(hgt, h->max_h), h->max_batch))) return rc;
+    }
     if ((rc = set_geometry(h, w, hgt))) return rc;
     const int pitch = h->geom.lv[0].pitch;
     const size_t fbytes = (size_t)pitch * hgt;
