@@ -139,36 +139,54 @@ def main():
     frames = synth.make_stream(1000 + rank, B, W, H)
     d_imgs = torch.from_numpy(frames).to(dev)
     nG = world * B  # frames visible to the matcher after the exchange
-    d_kps = torch.zeros((nG, cap, 28), dtype=torch.uint8, device=dev)
-    d_desc = torch.zeros((nG, cap, 32), dtype=torch.uint8, device=dev)
-    d_cnt = torch.zeros((nG,), dtype=torch.int32, device=dev)
     lo = rank * B
-    if world > 1:  # separate send buffers: the all-gather never aliases its own output
-        k_loc = torch.zeros((B, cap, 28), dtype=torch.uint8, device=dev)
-        d_loc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
-        c_loc = torch.zeros((B,), dtype=torch.int32, device=dev)
-    else:
-        k_loc, d_loc, c_loc = d_kps, d_desc, d_cnt
     from orbslam_in_practice_amd import shard
     pa_h, pb_h = shard.stream_pairs(rank, world, B)  # (k, k+1) in the global stream; the last one wraps
     pa = torch.from_numpy(pa_h).to(dev)
     pb = torch.from_numpy(pb_h).to(dev)
-    d_m12 = torch.full((B, cap), -1, dtype=torch.int32, device=dev)
-    d_nm = torch.zeros((B,), dtype=torch.int32, device=dev)
     bounds = (0.0, float(W), 0.0, float(H))
 
-    stream = torch.cuda.Stream(device=dev)
-    sp = C.c_void_p(stream.cuda_stream)
+    # Two HIP streams, double-buffered feature slabs: the (latency-bound) match of batch k runs on stream B
+    # while stream A already extracts batch k+1.
+    class Slab:
+        def __init__(self):
+            self.kps = torch.zeros((nG, cap, 28), dtype=torch.uint8, device=dev)
+            self.desc = torch.zeros((nG, cap, 32), dtype=torch.uint8, device=dev)
+            self.cnt = torch.zeros((nG,), dtype=torch.int32, device=dev)
+            if world > 1:  # separate send buffers: the all-gather never aliases its own output
+                self.k_loc = torch.zeros((B, cap, 28), dtype=torch.uint8, device=dev)
+                self.d_loc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+                self.c_loc = torch.zeros((B,), dtype=torch.int32, device=dev)
+            else:
+                self.k_loc, self.d_loc, self.c_loc = self.kps, self.desc, self.cnt
+            self.m12 = torch.full((B, cap), -1, dtype=torch.int32, device=dev)
+            self.nm = torch.zeros((B,), dtype=torch.int32, device=dev)
+            self.extracted = torch.cuda.Event()
+            self.matched = torch.cuda.Event()
+
+    slabs = [Slab(), Slab()]
+    sA = torch.cuda.Stream(device=dev)
+    sB = torch.cuda.Stream(device=dev)
+    pA, pB = C.c_void_p(sA.cuda_stream), C.c_void_p(sB.cuda_stream)
+    step_no = [0]
 
     def step():
-        ext.extract_batch_device(d_imgs.data_ptr(), B, W, H, W, W * H, k_loc.data_ptr(), d_loc.data_ptr(), cap,
-                                 c_loc.data_ptr(), sp)
-        if world > 1:  # the one exchange step of the path: fixed-capacity feature slabs over xGMI
-            all_gather_flat(d_kps, k_loc)
-            all_gather_flat(d_desc, d_loc)
-            all_gather_flat(d_cnt, c_loc)
-        matcher.match_batch_device(d_kps.data_ptr(), d_desc.data_ptr(), d_cnt.data_ptr(), cap, pa.data_ptr(),
-                                   pb.data_ptr(), B, bounds, -1, d_m12.data_ptr(), d_nm.data_ptr(), sp)
+        sl = slabs[step_no[0] & 1]
+        step_no[0] += 1
+        with torch.cuda.stream(sA):
+            sA.wait_event(sl.matched)  # the match that last read this slab has finished
+            ext.extract_batch_device(d_imgs.data_ptr(), B, W, H, W, W * H, sl.k_loc.data_ptr(), sl.d_loc.data_ptr(), cap,
+                                     sl.c_loc.data_ptr(), pA)
+            if world > 1:  # the one exchange step of the path: fixed-capacity feature slabs over xGMI
+                all_gather_flat(sl.kps, sl.k_loc)
+                all_gather_flat(sl.desc, sl.d_loc)
+                all_gather_flat(sl.cnt, sl.c_loc)
+            sl.extracted.record(sA)
+        with torch.cuda.stream(sB):
+            sB.wait_event(sl.extracted)
+            matcher.match_batch_device(sl.kps.data_ptr(), sl.desc.data_ptr(), sl.cnt.data_ptr(), cap, pa.data_ptr(),
+                                       pb.data_ptr(), B, bounds, -1, sl.m12.data_ptr(), sl.nm.data_ptr(), pB)
+            sl.matched.record(sB)
 
     def barrier():
         torch.cuda.synchronize()
@@ -176,7 +194,7 @@ def main():
             dist.barrier()
 
     L = oa._lib.lib()
-    with torch.cuda.stream(stream):
+    if True:
         for _ in range(args.warmup):
             step()
         barrier()
@@ -200,8 +218,8 @@ def main():
     oa._lib.check(L.orb_matcher_get_ms(matcher._m, C.byref(mm)))
     stage_ms = dict(zip(["pyramid", "fast", "quadtree", "blur", "describe"], [float(v) for v in ms5]))
     stage_ms["match"] = float(mm.value)
-    counts = c_loc.cpu().numpy()
-    nmatch = d_nm.cpu().numpy()
+    counts = slabs[0].c_loc.cpu().numpy()
+    nmatch = slabs[0].nm.cpu().numpy()
     n_kp = float(counts.mean())
 
     if rank == 0:

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -84,8 +85,12 @@ struct OrbExtractor {
     int last_frames = 0;
     bool profile = false;
     static const int kProfRing = 64;
-    hipEvent_t ev[64][6] = {};
+    hipEvent_t ev[64][8] = {};
     long prof_calls = 0;
+    /* the blur only needs the pyramid, so it runs on an auxiliary stream beside FAST + quadtree */
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool overlap = true;
 };
 
 /* reference src/ORBextractor.cpp:360-420 */
@@ -398,10 +403,14 @@ extern "C" int orb_create(const OrbConfig *cfg, int max_w, int max_h, int max_ba
         orb_destroy(h);
         return code;
     };
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
         g_err = "hipStreamCreate failed";
         return fail(ORB_E_HIP);
     }
+    h->overlap = getenv("ORBSLAM_AMD_NO_OVERLAP") == nullptr;
     if (orb_upload_constants() != hipSuccess) {
         g_err = "constant upload failed";
         return fail(ORB_E_HIP);
@@ -431,8 +440,11 @@ extern "C" void orb_destroy(OrbExtractor *h) {
     (void)hipFree(h->d_tab_c);
     free_staging(h);
     for (int r = 0; r < OrbExtractor::kProfRing; r++)
-        for (int i = 0; i < 6; i++)
+        for (int i = 0; i < 8; i++)
             if (h->ev[r][i]) (void)hipEventDestroy(h->ev[r][i]);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->aux) (void)hipStreamDestroy(h->aux);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -468,7 +480,7 @@ extern "C" int orb_set_profiling(OrbExtractor *h, int enable) {
     HIPCHK(hipSetDevice(h->device));
     if (enable && !h->ev[0][0])
         for (int r = 0; r < OrbExtractor::kProfRing; r++)
-            for (int i = 0; i < 6; i++) HIPCHK(hipEventCreate(&h->ev[r][i]));
+            for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&h->ev[r][i]));
     h->profile = enable != 0;
     h->prof_calls = 0;
     return ORB_OK;
@@ -481,9 +493,11 @@ extern "C" int orb_get_stage_ms(OrbExtractor *h, float *ms5) {
     for (int i = 0; i < 5; i++) ms5[i] = 0.f;
     for (int r = 0; r < n; r++) {
         HIPCHK(hipEventSynchronize(h->ev[r][5]));
+        HIPCHK(hipEventSynchronize(h->ev[r][7]));
+        static const int a[5] = {0, 1, 2, 6, 4}, b[5] = {1, 2, 3, 7, 5}; /* pyramid, FAST, quadtree, blur, describe */
         for (int i = 0; i < 5; i++) {
             float t = 0.f;
-            HIPCHK(hipEventElapsedTime(&t, h->ev[r][i], h->ev[r][i + 1]));
+            HIPCHK(hipEventElapsedTime(&t, h->ev[r][a[i]], h->ev[r][b[i]]));
             ms5[i] += t / n;
         }
     }
@@ -517,14 +531,32 @@ extern "C" int orb_extract_batch_device(OrbExtractor *h, const uint8_t *d_imgs, 
     const OrbGeom &g = h->geom;
     const bool prof = h->profile;
     hipEvent_t *ev = h->ev[h->prof_calls % OrbExtractor::kProfRing];
+    /* events: 0 start | 1 pyramid done | 2 FAST done | 3 quadtree done | 4 describe start | 5 describe done |
+               6 blur start (aux stream) | 7 blur done (aux stream) */
     if (prof) HIPCHK(hipEventRecord(ev[0], st));
     HIPCHK(launch_pyramid(g, h->buf, d_imgs, stride, frame_stride, n_frames, st));
     if (prof) HIPCHK(hipEventRecord(ev[1], st));
     HIPCHK(launch_fast(g, h->buf, n_frames, st));
     if (prof) HIPCHK(hipEventRecord(ev[2], st));
+    if (h->overlap) {
+        /* fork: the blur (throughput-bound, needs only the pyramid) runs on the auxiliary stream BESIDE the
+           quadtree (latency-bound: few resident wavefronts, mostly waiting), and is joined before describe */
+        HIPCHK(hipEventRecord(h->ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
+        if (prof) HIPCHK(hipEventRecord(ev[6], h->aux));
+        HIPCHK(launch_blur(g, h->buf, n_frames, h->aux));
+        if (prof) HIPCHK(hipEventRecord(ev[7], h->aux));
+        HIPCHK(hipEventRecord(h->ev_join, h->aux));
+    }
     HIPCHK(launch_quadtree(g, h->buf, n_frames, st));
     if (prof) HIPCHK(hipEventRecord(ev[3], st));
-    HIPCHK(launch_blur(g, h->buf, n_frames, st));
+    if (h->overlap) {
+        HIPCHK(hipStreamWaitEvent(st, h->ev_join, 0)); /* join */
+    } else {
+        if (prof) HIPCHK(hipEventRecord(ev[6], st));
+        HIPCHK(launch_blur(g, h->buf, n_frames, st));
+        if (prof) HIPCHK(hipEventRecord(ev[7], st));
+    }
     if (prof) HIPCHK(hipEventRecord(ev[4], st));
     HIPCHK(launch_describe(g, h->buf, n_frames, d_kps, d_desc, cap, d_counts, st));
     if (prof) HIPCHK(hipEventRecord(ev[5], st));
