@@ -46,40 +46,87 @@ __global__ __launch_bounds__(256) void k_copy_level0(OrbGeom g, uint8_t *pyr, co
 }
 
 /* ---- level l from level l-1, cv::resize INTER_LINEAR fixed point -------------------------------- */
+/* One workgroup = a 128 x 8 output tile.  The source rows/columns it touches ((8*s+2) x (128*s+2) pixels,
+ * s = scale step <= 2) are staged in LDS as aligned dwords (row-coalesced), then every thread produces 4
+ * adjacent pixels from LDS bytes and the packed per-column {sx, a0, a1} / per-row {sy, b0, b1} tables
+ * (one 8-byte table load per pixel instead of three), and stores one u32. */
+#define RS_TW 128
+#define RS_TH 8
+#define RS_LW 288 /* staged bytes per source row: 128 * 2 + slack, multiple of 4 */
+#define RS_LH 20  /* staged source rows: 8 * 2 + slack */
 __global__ __launch_bounds__(256) void k_resize(OrbGeom g, uint8_t *pyr, const int32_t *tab_i, const int16_t *tab_c,
                                                  int level) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_src[RS_LH][RS_LW];
     const LevelGeom &L = g.lv[level];
     const LevelGeom &S = g.lv[level - 1];
-    const int frame = blockIdx.z;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    if (y >= L.h || x0 >= L.w) return;
+    const int nbx = gridDim.x, nby = gridDim.y;
+    const int item = xcd_remap((blockIdx.z * nby + blockIdx.y) * nbx + blockIdx.x, nbx * nby * (int)gridDim.z);
+    const int frame = item / (nbx * nby), rem = item - frame * (nbx * nby);
+    const int by = rem / nbx, bx = rem - by * nbx;
+    const int tx0 = bx * RS_TW, ty0 = by * RS_TH;
+    const int tid = threadIdx.x;
     const uint8_t *src = level_ptr(pyr, g, frame, level - 1);
-    uint8_t *dst = level_ptr(pyr, g, frame, level) + (int64_t)y * L.pitch;
     const int32_t *xofs = tab_i + L.xofs_off;
     const int32_t *yofs = tab_i + L.yofs_off;
     const int16_t *ialpha = tab_c + 2 * L.xofs_off;
     const int16_t *ibeta = tab_c + 2 * L.yofs_off;
-    int sy = yofs[y];
-    int sy0 = min(max(sy, 0), S.h - 1), sy1 = min(max(sy + 1, 0), S.h - 1);
-    const uint8_t *r0 = src + (int64_t)sy0 * S.pitch;
-    const uint8_t *r1 = src + (int64_t)sy1 * S.pitch;
-    const int b0 = ibeta[2 * y], b1 = ibeta[2 * y + 1];
-    uint32_t packed = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        int x = x0 + i;
-        if (x < L.w) {
-            int sx = xofs[x];
-            int sx1 = min(sx + 1, S.w - 1);
-            int a0 = ialpha[2 * x], a1 = ialpha[2 * x + 1];
-            int h0 = r0[sx] * a0 + r0[sx1] * a1;
-            int h1 = r1[sx] * a0 + r1[sx1] * a1;
-            int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-            packed |= (uint32_t)(v & 0xFF) << (8 * i);
+    /* source window of this tile */
+    const int x_last = min(tx0 + RS_TW, L.w) - 1, y_last = min(ty0 + RS_TH, L.h) - 1;
+    const int sx_lo = xofs[tx0] & ~3;                                   /* xofs is non-decreasing and >= 0 */
+    const int sx_hi = min(xofs[x_last] + 1, S.w - 1);
+    const int sy_lo = min(max(yofs[ty0], 0), S.h - 1);
+    const int sy_hi = min(max(yofs[y_last] + 1, 0), S.h - 1);
+    const int ndw = (sx_hi - sx_lo) / 4 + 1, nrow = sy_hi - sy_lo + 1;
+    if (ndw * 4 <= RS_LW && nrow <= RS_LH) {
+        for (int i = tid; i < nrow * ndw; i += 256) {
+            const int r = i / ndw, c4 = i - r * ndw;
+            /* the pitch is a multiple of 64 and planes are 256-B aligned: the dword stays inside the plane */
+            *(uint32_t *)&s_src[r][c4 * 4] = *(const uint32_t *)(src + (int64_t)(sy_lo + r) * S.pitch + sx_lo + c4 * 4);
         }
+        __syncthreads();
+        const int y = ty0 + (tid >> 5), x0 = tx0 + (tid & 31) * 4;
+        if (y >= L.h || x0 >= L.w) return;
+        const int sy = yofs[y];
+        const int r0 = min(max(sy, 0), S.h - 1) - sy_lo, r1 = min(max(sy + 1, 0), S.h - 1) - sy_lo;
+        const int b0 = ibeta[2 * y], b1 = ibeta[2 * y + 1];
+        uint32_t packed = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int x = x0 + i;
+            if (x < L.w) {
+                const int sx = xofs[x];
+                const int c0 = sx - sx_lo, c1 = min(sx + 1, S.w - 1) - sx_lo;
+                const int a0 = ialpha[2 * x], a1 = ialpha[2 * x + 1];
+                const int h0 = s_src[r0][c0] * a0 + s_src[r0][c1] * a1;
+                const int h1 = s_src[r1][c0] * a0 + s_src[r1][c1] * a1;
+                const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                packed |= (uint32_t)(v & 0xFF) << (8 * i);
+            }
+        }
+        *(uint32_t *)(level_ptr(pyr, g, frame, level) + (int64_t)y * L.pitch + x0) = packed;
+        return;
     }
-    *(uint32_t *)(dst + x0) = packed;
+    /* generic path (scale steps > 2 between levels: the window does not fit the LDS tile): direct gathers */
+    {
+        const int y = ty0 + (tid >> 5), x0 = tx0 + (tid & 31) * 4;
+        if (y >= L.h || x0 >= L.w) return;
+        const int sy = yofs[y];
+        const uint8_t *r0 = src + (int64_t)min(max(sy, 0), S.h - 1) * S.pitch;
+        const uint8_t *r1 = src + (int64_t)min(max(sy + 1, 0), S.h - 1) * S.pitch;
+        const int b0 = ibeta[2 * y], b1 = ibeta[2 * y + 1];
+        uint32_t packed = 0;
+        for (int i = 0; i < 4; i++) {
+            const int x = x0 + i;
+            if (x < L.w) {
+                const int sx = xofs[x], sx1 = min(sx + 1, S.w - 1);
+                const int a0 = ialpha[2 * x], a1 = ialpha[2 * x + 1];
+                const int h0 = r0[sx] * a0 + r0[sx1] * a1, h1 = r1[sx] * a0 + r1[sx1] * a1;
+                const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                packed |= (uint32_t)(v & 0xFF) << (8 * i);
+            }
+        }
+        *(uint32_t *)(level_ptr(pyr, g, frame, level) + (int64_t)y * L.pitch + x0) = packed;
+    }
 }
 
 /* ---- 7x7 Gaussian blur, all levels in one launch -------------------------------------------------- */
@@ -185,7 +232,7 @@ hipError_t launch_pyramid(const OrbGeom &g, const OrbBuffers &b, const uint8_t *
     dim3 grid0((g.w + 1023) / 1024, (g.h + 3) / 4, n_frames);
     hipLaunchKernelGGL(k_copy_level0, grid0, dim3(256), 0, st, g, b.pyr, d_imgs, stride, frame_stride, vec16);
     for (int l = 1; l < g.nlevels; l++) {
-        dim3 grid((g.lv[l].w + 255) / 256, (g.lv[l].h + 3) / 4, n_frames);
+        dim3 grid((g.lv[l].w + RS_TW - 1) / RS_TW, (g.lv[l].h + RS_TH - 1) / RS_TH, n_frames);
         hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, g, b.pyr, b.tab_i, b.tab_c, l);
     }
     return hipGetLastError();
