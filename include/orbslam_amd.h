@@ -204,6 +204,12 @@ int ba_solve_batch(BASolver *s, const BAProblem *p, BAResult *r, int n);
 int ba_pose_optimization(BASolver *s, double *pose, const double *xw, const double *obs,
                          const double *inv_sigma2, int n, double fx, double fy, double cx, double cy,
                          uint8_t *outlier, int32_t *n_inliers);
+/* n_problems independent pose problems in one launch (Tracking calls PoseOptimization up to three times per
+ * frame: src/Tracking.cpp:309,355,382).  Problem p owns edges [offsets[p], offsets[p+1]) of xw / obs /
+ * inv_sigma2 / outlier; poses[7*n_problems] in/out; n_inliers[n_problems] out. */
+int ba_pose_optimization_batch(BASolver *s, double *poses, const double *xw, const double *obs,
+                               const double *inv_sigma2, const int32_t *offsets, int n_problems, double fx, double fy,
+                               double cx, double cy, uint8_t *outlier, int32_t *n_inliers);
 
 #ifdef __cplusplus
 }

@@ -61,7 +61,7 @@ EXPORTS = [
     "orb_set_profiling", "orb_get_stage_ms", "orb_matcher_set_profiling", "orb_matcher_get_ms",
     "orb_descriptor_distance", "orb_compute_three_maxima", "orb_matcher_create", "orb_matcher_destroy",
     "orb_matcher_stream", "orb_matcher_synchronize", "orb_hamming_knn2", "orb_match_init",
-    "orb_match_batch_device", "ba_create", "ba_destroy", "ba_solve", "ba_solve_batch", "ba_pose_optimization",
+    "orb_match_batch_device", "ba_create", "ba_destroy", "ba_solve", "ba_solve_batch", "ba_pose_optimization", "ba_pose_optimization_batch",
 ]
 
 _lib = None
@@ -126,6 +126,8 @@ def lib():
     L.ba_solve_batch.argtypes = [vp, C.POINTER(BAProblem), C.POINTER(BAResult), i32]
     L.ba_pose_optimization.argtypes = [vp, vp, vp, vp, vp, i32, C.c_double, C.c_double, C.c_double, C.c_double,
                                        vp, vp]
+    L.ba_pose_optimization_batch.argtypes = [vp, vp, vp, vp, vp, vp, i32, C.c_double, C.c_double, C.c_double,
+                                             C.c_double, vp, vp]
     _lib = L
     return L
 

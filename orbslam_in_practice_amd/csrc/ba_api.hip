@@ -1168,11 +1168,23 @@ __device__ double po_chi2(const double *pose, const double *xw, const double *ob
     return out;
 }
 
-__global__ __launch_bounds__(PO_T) void k_pose_opt(double *pose7, const double *xw, const double *obs, const double *info,
-                                                    uint8_t *fl, uint8_t *outlier, int n, double fx, double fy, double cx,
-                                                    double cy, int32_t *n_inliers) {
+__global__ __launch_bounds__(PO_T) void k_pose_opt(double *pose7_all, const double *xw_all, const double *obs_all,
+                                                    const double *info_all, uint8_t *fl_all, uint8_t *outlier_all,
+                                                    const int32_t *offs, double fx, double fy, double cx, double cy,
+                                                    int32_t *n_inliers_all) {
+    /* one workgroup per pose problem: problem p owns edges [offs[p], offs[p+1]) */
     __shared__ POShared s;
     const int tid = threadIdx.x;
+    const int e0 = offs[blockIdx.x], n = offs[blockIdx.x + 1] - e0;
+    double *pose7 = pose7_all + (int64_t)blockIdx.x * 7;
+    const double *xw = xw_all + (int64_t)e0 * 3, *obs = obs_all + (int64_t)e0 * 2, *info = info_all + e0;
+    uint8_t *fl = fl_all + e0, *outlier = outlier_all + e0;
+    int32_t *n_inliers = n_inliers_all + blockIdx.x;
+    if (n < 3) { /* src/Optimizer.cpp:206-207: returns 0, pose untouched */
+        if (tid == 0) *n_inliers = 0;
+        if (tid < n) outlier[tid] = 0;
+        return;
+    }
     const double delta = 5.99;
     if (tid < 7) s.pose[tid] = pose7[tid];
     for (int i = tid; i < n; i += PO_T) {
@@ -1323,29 +1335,47 @@ __global__ __launch_bounds__(PO_T) void k_pose_opt(double *pose7, const double *
     if (tid == 0) *n_inliers = n - nBads;
 }
 
+/* n_problems independent pose problems; problem p owns edges [offsets[p], offsets[p+1]) of xw/obs/inv_sigma2/
+ * outlier; poses[7*n_problems] in/out; n_inliers[n_problems] out.  One launch, one workgroup per problem. */
+extern "C" int ba_pose_optimization_batch(BASolver *s, double *poses, const double *xw, const double *obs,
+                                          const double *inv_sigma2, const int32_t *offsets, int n_problems, double fx,
+                                          double fy, double cx, double cy, uint8_t *outlier, int32_t *n_inliers) {
+    if (!s || !poses || !offsets || !n_inliers || n_problems <= 0) return ORB_E_INVALID;
+    const int n = offsets[n_problems];
+    if (n < 0 || (n > 0 && (!xw || !obs || !inv_sigma2 || !outlier))) return ORB_E_INVALID;
+    for (int p = 0; p < n_problems; p++)
+        if (offsets[p + 1] < offsets[p]) return ORB_E_INVALID;
+    BCHK(hipSetDevice(s->device));
+    int rc;
+    const size_t nd = (size_t)n_problems * 7 + (size_t)n * 6 + 8, nb = (size_t)n * 2 + 16;
+    if ((rc = ba_grow(s->dD, s->capD, nd))) return rc;
+    if ((rc = ba_grow(s->dB, s->capB, nb))) return rc;
+    if ((rc = ba_grow(s->dI, s->capI, (size_t)2 * n_problems + 4))) return rc;
+    double *d_pose = s->dD, *d_xw = d_pose + (((size_t)n_problems * 7 + 1) & ~(size_t)1), *d_obs = d_xw + (size_t)n * 3,
+           *d_info = d_obs + (size_t)n * 2;
+    uint8_t *d_fl = s->dB, *d_out = s->dB + n + 8;
+    int32_t *d_offs = s->dI, *d_ninl = s->dI + n_problems + 1;
+    BCHK(hipMemcpyAsync(d_pose, poses, (size_t)n_problems * 56, hipMemcpyHostToDevice, s->stream));
+    BCHK(hipMemcpyAsync(d_offs, offsets, (size_t)(n_problems + 1) * 4, hipMemcpyHostToDevice, s->stream));
+    if (n > 0) {
+        BCHK(hipMemcpyAsync(d_xw, xw, (size_t)n * 24, hipMemcpyHostToDevice, s->stream));
+        BCHK(hipMemcpyAsync(d_obs, obs, (size_t)n * 16, hipMemcpyHostToDevice, s->stream));
+        BCHK(hipMemcpyAsync(d_info, inv_sigma2, (size_t)n * 8, hipMemcpyHostToDevice, s->stream));
+    }
+    hipLaunchKernelGGL(k_pose_opt, dim3(n_problems), dim3(PO_T), 0, s->stream, d_pose, (const double *)d_xw,
+                       (const double *)d_obs, (const double *)d_info, d_fl, d_out, (const int32_t *)d_offs, fx, fy, cx, cy,
+                       d_ninl);
+    BCHK(hipGetLastError());
+    BCHK(hipMemcpyAsync(poses, d_pose, (size_t)n_problems * 56, hipMemcpyDeviceToHost, s->stream));
+    if (n > 0) BCHK(hipMemcpyAsync(outlier, d_out, (size_t)n, hipMemcpyDeviceToHost, s->stream));
+    BCHK(hipMemcpyAsync(n_inliers, d_ninl, (size_t)n_problems * 4, hipMemcpyDeviceToHost, s->stream));
+    BCHK(hipStreamSynchronize(s->stream));
+    return ORB_OK;
+}
+
 extern "C" int ba_pose_optimization(BASolver *s, double *pose, const double *xw, const double *obs, const double *inv_sigma2,
                                     int n, double fx, double fy, double cx, double cy, uint8_t *outlier, int32_t *n_inliers) {
     if (!s || !pose || !n_inliers || n < 0 || (n > 0 && (!xw || !obs || !inv_sigma2 || !outlier))) return ORB_E_INVALID;
-    *n_inliers = 0;
-    if (n < 3) return ORB_OK; /* src/Optimizer.cpp:206-207 */
-    BCHK(hipSetDevice(s->device));
-    int rc;
-    const size_t nd = 8 + (size_t)n * 6 + 2, nb = (size_t)n * 2 + 16;
-    if ((rc = ba_grow(s->dD, s->capD, nd))) return rc;
-    if ((rc = ba_grow(s->dB, s->capB, nb))) return rc;
-    if ((rc = ba_grow(s->dI, s->capI, 4))) return rc;
-    double *d_pose = s->dD, *d_xw = s->dD + 8, *d_obs = d_xw + (size_t)n * 3, *d_info = d_obs + (size_t)n * 2;
-    uint8_t *d_fl = s->dB, *d_out = s->dB + n;
-    BCHK(hipMemcpyAsync(d_pose, pose, 7 * 8, hipMemcpyHostToDevice, s->stream));
-    BCHK(hipMemcpyAsync(d_xw, xw, (size_t)n * 24, hipMemcpyHostToDevice, s->stream));
-    BCHK(hipMemcpyAsync(d_obs, obs, (size_t)n * 16, hipMemcpyHostToDevice, s->stream));
-    BCHK(hipMemcpyAsync(d_info, inv_sigma2, (size_t)n * 8, hipMemcpyHostToDevice, s->stream));
-    hipLaunchKernelGGL(k_pose_opt, dim3(1), dim3(PO_T), 0, s->stream, d_pose, (const double *)d_xw, (const double *)d_obs,
-                       (const double *)d_info, d_fl, d_out, n, fx, fy, cx, cy, s->dI);
-    BCHK(hipGetLastError());
-    BCHK(hipMemcpyAsync(pose, d_pose, 7 * 8, hipMemcpyDeviceToHost, s->stream));
-    BCHK(hipMemcpyAsync(outlier, d_out, (size_t)n, hipMemcpyDeviceToHost, s->stream));
-    BCHK(hipMemcpyAsync(n_inliers, s->dI, 4, hipMemcpyDeviceToHost, s->stream));
-    BCHK(hipStreamSynchronize(s->stream));
-    return ORB_OK;
+    const int32_t offs[2] = {0, n};
+    return ba_pose_optimization_batch(s, pose, xw, obs, inv_sigma2, offs, 1, fx, fy, cx, cy, outlier, n_inliers);
 }

@@ -104,6 +104,24 @@ class Optimizer:
         return pose, outlier[:n], ninl.value
 
 
+    def PoseOptimizationBatch(self, poses, xws, obss, infos, fx, fy, cx, cy):
+        """several pose problems in one launch (ba_pose_optimization_batch).  poses [P,7]; xws/obss/infos lists
+        of per-problem arrays.  Returns (poses, [outlier arrays], n_inliers[P])."""
+        P = len(xws)
+        poses = np.ascontiguousarray(poses, np.float64).reshape(P, 7).copy()
+        offs = np.zeros(P + 1, np.int32)
+        offs[1:] = np.cumsum([len(x) for x in xws])
+        n = int(offs[-1])
+        xw = np.ascontiguousarray(np.concatenate(xws) if n else np.zeros((0, 3)), np.float64)
+        obs = np.ascontiguousarray(np.concatenate(obss) if n else np.zeros((0, 2)), np.float64)
+        info = np.ascontiguousarray(np.concatenate(infos) if n else np.zeros(0), np.float64)
+        outlier = np.zeros(max(n, 1), np.uint8)
+        ninl = np.zeros(P, np.int32)
+        check(self._L.ba_pose_optimization_batch(self._s, ptr(poses), ptr(xw), ptr(obs), ptr(info), ptr(offs), P, fx, fy,
+                                                 cx, cy, ptr(outlier), ptr(ninl)))
+        return poses, [outlier[offs[i]:offs[i + 1]] for i in range(P)], ninl
+
+
 def solve_window(window, rounds=(5, 10), **kw):
     o = Optimizer()
     try:

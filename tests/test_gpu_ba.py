@@ -108,3 +108,24 @@ def test_pose_optimization(opt, oracle):
     # fewer than 3 correspondences: returns 0 and leaves the pose alone (src/Optimizer.cpp:206-207)
     gp2, _, gn2 = opt.PoseOptimization(pose0, xw[:2], obs[:2], info[:2], w["fx"], w["fy"], w["cx"], w["cy"])
     assert gn2 == 0 and np.array_equal(gp2, pose0)
+
+
+def test_pose_optimization_batch(opt, oracle):
+    """N3: several frames' pose problems in one launch equal the oracle one by one (ragged sizes, one tiny)"""
+    from orbslam_in_practice_amd import synth
+    w = synth.make_ba_window(21, 8, 500, outlier_frac=0.08)
+    poses, xws, obss, infos = [], [], [], []
+    for c in range(1, 7):
+        sel = w["cam_idx"] == c
+        if c == 4:
+            sel = sel & (np.cumsum(sel) <= 2)      # fewer than 3 correspondences
+        poses.append(w["poses"][c])
+        xws.append(w["gt_points"][w["pt_idx"][sel]])
+        obss.append(w["obs"][sel])
+        infos.append(w["inv_sigma2"][sel])
+    gp, go, gn = opt.PoseOptimizationBatch(np.array(poses), xws, obss, infos, w["fx"], w["fy"], w["cx"], w["cy"])
+    for i in range(6):
+        rp, ro, rn = oracle.pose_optimization(poses[i], xws[i], obss[i], infos[i], w["fx"], w["fy"], w["cx"], w["cy"])
+        assert gn[i] == rn and np.array_equal(go[i], ro[:len(go[i])])
+        assert np.abs(gp[i] - rp).max() < REL * max(np.abs(rp).max(), 1.0)
+    assert gn[3] == 0 and np.array_equal(gp[3], poses[3])
