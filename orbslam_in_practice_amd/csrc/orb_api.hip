@@ -251,6 +251,8 @@ static int build_geom(OrbExtractor *h, int w, int hgt) {
                     }
                     h->h_cells.push_back(c);
                     L.n_cells++;
+                    g.cell_max_rw = std::max<int>(g.cell_max_rw, c.rw);
+                    g.cell_max_rh = std::max<int>(g.cell_max_rh, c.rh);
                 }
             }
             /* quadtree roots, src/ORBextractor.cpp:493-495 */

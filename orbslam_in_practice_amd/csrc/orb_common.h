@@ -44,6 +44,7 @@ struct OrbGeom {
     int nlevels, w, h;
     int ini_th, min_th;
     int total_cells;
+    int cell_max_rw, cell_max_rh; /* largest FAST cell ROI of this geometry (sizes the LDS tile) */
     int total_out_cap;        /* sum of out_cap                                                     */
     int64_t pyr_frame_bytes;  /* bytes of one frame's pyramid block (all levels)                   */
     int64_t key_frame_count;  /* keys of one frame's candidate block (all levels)                  */

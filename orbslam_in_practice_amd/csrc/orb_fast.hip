@@ -164,9 +164,136 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells(OrbGeom g, const uint8_t 
     if (tid == 255) cell_cnt[(int64_t)frame * g.total_cells + cell] = base + incl;
 }
 
+
+/* cornerScore with a run-time LDS row pitch (same packed network as fast_score16) */
+__device__ __forceinline__ int fast_score16_ld(const uint8_t *c, int v, int ld) {
+    const uint8_t *rm3 = c - 3 * ld, *rm2 = c - 2 * ld, *rm1 = c - ld, *rp1 = c + ld, *rp2 = c + 2 * ld, *rp3 = c + 3 * ld;
+    int d[16];
+    d[0] = v - rp3[0];
+    d[1] = v - rp3[1];
+    d[2] = v - rp2[2];
+    d[3] = v - rp1[3];
+    d[4] = v - c[3];
+    d[5] = v - rm1[3];
+    d[6] = v - rm2[2];
+    d[7] = v - rm3[1];
+    d[8] = v - rm3[0];
+    d[9] = v - rm3[-1];
+    d[10] = v - rm2[-2];
+    d[11] = v - rm1[-3];
+    d[12] = v - c[-3];
+    d[13] = v - rp1[-3];
+    d[14] = v - rp2[-2];
+    d[15] = v - rp3[-1];
+    v2s p[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        p[k].x = (short)d[k];
+        p[k].y = (short)(-d[k]);
+    }
+    v2s w2[16], w4[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) w2[k] = __builtin_elementwise_min(p[k], p[(k + 1) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) w4[k] = __builtin_elementwise_min(w2[k], w2[(k + 2) & 15]);
+    v2s best = {-1000, -1000};
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        v2s w9 = __builtin_elementwise_min(__builtin_elementwise_min(w4[k], w4[(k + 4) & 15]), p[(k + 8) & 15]);
+        best = __builtin_elementwise_max(best, w9);
+    }
+    return max((int)best.x, (int)best.y) - 1;
+}
+
+/* ONE WAVEFRONT per (cell, frame): a 64-thread workgroup, LDS tile sized to the largest cell of the current
+ * geometry (about 3 KB at 640x480), ROI staged as aligned dwords.  No cross-wave barrier, no workgroup scan:
+ * ordered emission is a running ballot/popcount prefix over 64-pixel row-major chunks. */
+#define FW_MAXCH 64 /* 64-px chunks per cell: 59*59/64 < 55 */
+__global__ __launch_bounds__(64) void k_fast_cells_wave(OrbGeom g, const uint8_t *pyr, const CellDesc *cells, uint32_t *slab,
+                                                        int32_t *cell_cnt, int ld, int lh) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t fw_smem[];
+    uint8_t *s_px = fw_smem;            /* [lh][ld], column 0 <-> x = iniX & ~3 */
+    uint8_t *s_sc = fw_smem + ld * lh;  /* scores, same layout */
+    const int item = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int frame = item / g.total_cells, cell = item - frame * g.total_cells;
+    const CellDesc cd = cells[cell];
+    const LevelGeom &L = g.lv[cd.level];
+    const int rw = cd.rw, rh = cd.rh, lane = threadIdx.x;
+    const int ox = cd.iniX & 3;
+    const uint8_t *src = level_ptr(pyr, g, frame, cd.level) + (int64_t)cd.iniY * L.pitch + (cd.iniX & ~3);
+    const int ndw = (ox + rw + 3) >> 2; /* aligned dwords per ROI row (the pitch is a multiple of 64) */
+    for (int i = lane; i < rh * ndw; i += 64) {
+        const int r = i / ndw, c4 = i - r * ndw;
+        *(uint32_t *)(s_px + r * ld + c4 * 4) = *(const uint32_t *)(src + (int64_t)r * L.pitch + c4 * 4);
+    }
+    for (int i = lane; i < (ld * lh) >> 2; i += 64) ((uint32_t *)s_sc)[i] = 0u;
+    __syncthreads();
+    const int iw = rw - 6, ih = rh - 6;
+    const int n_in = (iw > 0 && ih > 0) ? iw * ih : 0;
+    const float inv_iw = 1.0f / (float)(iw > 0 ? iw : 1);
+    const int nch = (n_in + 63) >> 6;
+    /* scores */
+    for (int ch = 0; ch < nch; ch++) {
+        const int i = ch * 64 + lane;
+        if (i < n_in) {
+            const int y = (int)(((float)i + 0.5f) * inv_iw), x = i - y * iw;
+            const uint8_t *c = s_px + (y + 3) * ld + (x + 3 + ox);
+            const int sc = fast_score16_ld(c, (int)c[0], ld);
+            s_sc[(y + 3) * ld + (x + 3 + ox)] = (uint8_t)(sc >= g.min_th ? sc : 0);
+        }
+    }
+    __syncthreads();
+    /* NMS per chunk; the keep flags (bit0: kept, bit1: kept and >= iniThFAST) go into the pixel tile, which
+       is no longer needed once the scores exist */
+    bool any_ini = false;
+#pragma unroll 1
+    for (int ch = 0; ch < nch; ch++) {
+        const int i = ch * 64 + lane;
+        bool ki = false;
+        if (i < n_in) {
+            const int y = (int)(((float)i + 0.5f) * inv_iw), x = i - y * iw;
+            const int pos = (y + 3) * ld + (x + 3 + ox);
+            const uint8_t *q = s_sc + pos;
+            const int sv = q[0];
+            const bool k = sv > 0 && sv > q[-ld - 1] && sv > q[-ld] && sv > q[-ld + 1] && sv > q[-1] && sv > q[1] &&
+                           sv > q[ld - 1] && sv > q[ld] && sv > q[ld + 1];
+            ki = k && sv >= g.ini_th;
+            s_px[pos] = (uint8_t)((k ? 1 : 0) | (ki ? 2 : 0));
+        }
+        any_ini = any_ini || (__ballot(ki) != 0);
+    }
+    __syncthreads();
+    uint32_t *out = slab + (int64_t)frame * g.slab_frame_count + cd.slab_off;
+    const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int want = any_ini ? 2 : 1; /* per-cell threshold fallback (:765-773) */
+    int base = 0;
+#pragma unroll 1
+    for (int ch = 0; ch < nch; ch++) {
+        const int i = ch * 64 + lane;
+        bool sel = false;
+        int x = 0, y = 0, pos = 0;
+        if (i < n_in) {
+            y = (int)(((float)i + 0.5f) * inv_iw);
+            x = i - y * iw;
+            pos = (y + 3) * ld + (x + 3 + ox);
+            sel = (s_px[pos] & want) != 0;
+        }
+        const uint64_t m = __ballot(sel);
+        if (sel) out[base + __popcll(m & lt)] = KEY_PACK(x + 3 + cd.offX, y + 3 + cd.offY, s_sc[pos]);
+        base += __popcll(m);
+    }
+    if (lane == 0) cell_cnt[(int64_t)frame * g.total_cells + cell] = base;
+}
+
 hipError_t launch_fast(const OrbGeom &g, const OrbBuffers &b, int n_frames, hipStream_t st) {
     if (g.total_cells == 0) return hipSuccess;
     dim3 grid(g.total_cells, n_frames);
+    if (g.cell_max_rw > 0) { /* one wavefront per cell */
+        const int ld = (g.cell_max_rw + 3 + 3) & ~3, lh = g.cell_max_rh;
+        hipLaunchKernelGGL(k_fast_cells_wave, grid, dim3(64), (size_t)2 * ld * lh, st, g, (const uint8_t *)b.pyr, b.cells, b.slab,
+                           b.cell_cnt, ld, lh);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, st, g, (const uint8_t *)b.pyr, b.cells, b.slab, b.cell_cnt);
     return hipGetLastError();
 }
