@@ -712,6 +712,11 @@ struct BASolver {
     uint8_t *dB = nullptr;
     BAWin *dW = nullptr;
     size_t capD = 0, capI = 0, capB = 0, capW = 0;
+    /* pinned host staging (H2D from pageable memory runs at a fraction of the PCIe rate) */
+    double *pD = nullptr;
+    int32_t *pI = nullptr;
+    uint8_t *pB = nullptr;
+    size_t pcapD = 0, pcapI = 0, pcapB = 0;
     double pcg_tol2 = 1e-26; /* relative M^-1-norm of the residual, squared */
 };
 
@@ -748,6 +753,9 @@ extern "C" void ba_destroy(BASolver *s) {
     (void)hipFree(s->dI);
     (void)hipFree(s->dB);
     (void)hipFree(s->dW);
+    if (s->pD) (void)hipHostFree(s->pD);
+    if (s->pI) (void)hipHostFree(s->pI);
+    if (s->pB) (void)hipHostFree(s->pB);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -758,6 +766,17 @@ template <typename T> static int ba_grow(T *&p, size_t &cap, size_t need) {
     p = nullptr;
     cap = 0;
     BCHK(hipMalloc((void **)&p, std::max<size_t>(need * sizeof(T), 256)));
+    cap = need;
+    return ORB_OK;
+}
+
+template <typename T> static int ba_grow_pinned(T *&p, size_t &cap, size_t need) {
+    if (need <= cap && p) return ORB_OK;
+    if (p) BCHK(hipHostFree(p));
+    p = nullptr;
+    cap = 0;
+    need += need / 4; /* head-room: batches of similar windows do not re-allocate */
+    BCHK(hipHostMalloc((void **)&p, std::max<size_t>(need * sizeof(T), 256)));
     cap = need;
     return ORB_OK;
 }
@@ -980,9 +999,7 @@ extern "C" int ba_solve_batch(BASolver *s, const BAProblem *probs, BAResult *res
         }
         if (!res[i].poses || (probs[i].n_points && !res[i].points)) return ORB_E_INVALID;
     }
-    std::vector<double> hD;
-    std::vector<int32_t> hI;
-    std::vector<uint8_t> hB;
+    size_t hD_n = 0, hI_n = 0, hB_n = 0; /* element counts of the pinned staging buffers s->pD / pI / pB */
     const bool prof = getenv("ORBSLAM_AMD_BA_PROFILE") != nullptr;
     auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_start = tnow();
@@ -1013,40 +1030,55 @@ extern "C" int ba_solve_batch(BASolver *s, const BAProblem *probs, BAResult *res
             for (auto &th : pool) th.join();
         }
         size_t nD = 0, nI = 0, nB = 0;
+        std::vector<size_t> oDs(nwin), oIs(nwin), oBs(nwin);
         for (int i = 0; i < nwin; i++) {
             if (pieces[i].rc) return pieces[i].rc;
+            oDs[i] = nD;
+            oIs[i] = nI;
+            oBs[i] = nB;
             nD += pieces[i].D.size();
             nI += pieces[i].I.size();
             nB += pieces[i].B.size();
         }
-        hD.resize(nD);
-        hI.resize(nI);
-        hB.resize(nB);
-        size_t oD = 0, oI = 0, oB = 0;
+        int rcp;
+        if ((rcp = ba_grow_pinned(s->pD, s->pcapD, nD))) return rcp;
+        if ((rcp = ba_grow_pinned(s->pI, s->pcapI, std::max<size_t>(nI, 1)))) return rcp;
+        if ((rcp = ba_grow_pinned(s->pB, s->pcapB, std::max<size_t>(nB, 1)))) return rcp;
+        hD_n = nD;
+        hI_n = nI;
+        hB_n = nB;
+        auto merge = [&](int t) {
+            for (int i = t; i < nwin; i += nthr) {
+                Piece &pc = pieces[i];
+                memcpy(s->pD + oDs[i], pc.D.data(), pc.D.size() * sizeof(double));
+                memcpy(s->pI + oIs[i], pc.I.data(), pc.I.size() * sizeof(int32_t));
+                memcpy(s->pB + oBs[i], pc.B.data(), pc.B.size());
+            }
+        };
+        if (nthr == 1)
+            merge(0);
+        else {
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nthr; t++) pool.emplace_back(merge, t);
+            for (auto &th : pool) th.join();
+        }
         for (int i = 0; i < nwin; i++) {
-            Piece &pc = pieces[i];
-            std::copy(pc.D.begin(), pc.D.end(), hD.begin() + oD);
-            std::copy(pc.I.begin(), pc.I.end(), hI.begin() + oI);
-            std::copy(pc.B.begin(), pc.B.end(), hB.begin() + oB);
-            for (auto f : kInputDFields) hw[i].w.*f += (int64_t)oD;
-            for (auto f : kIntFields) hw[i].w.*f += (int64_t)oI;
-            hw[i].w.flags += (int64_t)oB;
+            for (auto f : kInputDFields) hw[i].w.*f += (int64_t)oDs[i];
+            for (auto f : kIntFields) hw[i].w.*f += (int64_t)oIs[i];
+            hw[i].w.flags += (int64_t)oBs[i];
             for (auto f : kScratchFields) hw[i].w.*f += (int64_t)(nD + scratchD);
-            scratchD += pc.scratch;
-            oD += pc.D.size();
-            oI += pc.I.size();
-            oB += pc.B.size();
+            scratchD += pieces[i].scratch;
             wins[i] = hw[i].w;
         }
     }
     int rc;
-    if ((rc = ba_grow(s->dD, s->capD, hD.size() + scratchD))) return rc;
-    if ((rc = ba_grow(s->dI, s->capI, std::max<size_t>(hI.size(), 1)))) return rc;
-    if ((rc = ba_grow(s->dB, s->capB, std::max<size_t>(hB.size(), 1)))) return rc;
+    if ((rc = ba_grow(s->dD, s->capD, hD_n + scratchD))) return rc;
+    if ((rc = ba_grow(s->dI, s->capI, std::max<size_t>(hI_n, 1)))) return rc;
+    if ((rc = ba_grow(s->dB, s->capB, std::max<size_t>(hB_n, 1)))) return rc;
     if ((rc = ba_grow(s->dW, s->capW, (size_t)nwin))) return rc;
-    BCHK(hipMemcpyAsync(s->dD, hD.data(), hD.size() * 8, hipMemcpyHostToDevice, s->stream));
-    if (!hI.empty()) BCHK(hipMemcpyAsync(s->dI, hI.data(), hI.size() * 4, hipMemcpyHostToDevice, s->stream));
-    if (!hB.empty()) BCHK(hipMemcpyAsync(s->dB, hB.data(), hB.size(), hipMemcpyHostToDevice, s->stream));
+    BCHK(hipMemcpyAsync(s->dD, s->pD, hD_n * 8, hipMemcpyHostToDevice, s->stream));
+    if (hI_n) BCHK(hipMemcpyAsync(s->dI, s->pI, hI_n * 4, hipMemcpyHostToDevice, s->stream));
+    if (hB_n) BCHK(hipMemcpyAsync(s->dB, s->pB, hB_n, hipMemcpyHostToDevice, s->stream));
     BCHK(hipMemcpyAsync(s->dW, wins.data(), (size_t)nwin * sizeof(BAWin), hipMemcpyHostToDevice, s->stream));
     BABufs bufs{s->dD, s->dI, s->dB, s->dW};
     if (prof) BCHK(hipStreamSynchronize(s->stream));
@@ -1090,29 +1122,29 @@ extern "C" int ba_solve_batch(BASolver *s, const BAProblem *probs, BAResult *res
     /* results */
     for (int i = 0; i < nwin; i++) { /* only poses, points and the LM state come back */
         const BAWin &w = wins[i];
-        BCHK(hipMemcpyAsync(&hD[w.poses], s->dD + w.poses, (size_t)w.Nc * 7 * 8, hipMemcpyDeviceToHost, s->stream));
-        if (w.Np) BCHK(hipMemcpyAsync(&hD[w.pts], s->dD + w.pts, (size_t)w.Np * 3 * 8, hipMemcpyDeviceToHost, s->stream));
-        BCHK(hipMemcpyAsync(&hD[w.st], s->dD + w.st, (size_t)ST_COUNT * 8, hipMemcpyDeviceToHost, s->stream));
+        BCHK(hipMemcpyAsync(&s->pD[w.poses], s->dD + w.poses, (size_t)w.Nc * 7 * 8, hipMemcpyDeviceToHost, s->stream));
+        if (w.Np) BCHK(hipMemcpyAsync(&s->pD[w.pts], s->dD + w.pts, (size_t)w.Np * 3 * 8, hipMemcpyDeviceToHost, s->stream));
+        BCHK(hipMemcpyAsync(&s->pD[w.st], s->dD + w.st, (size_t)ST_COUNT * 8, hipMemcpyDeviceToHost, s->stream));
     }
-    if (!hB.empty()) BCHK(hipMemcpyAsync(hB.data(), s->dB, hB.size(), hipMemcpyDeviceToHost, s->stream));
+    if (hB_n) BCHK(hipMemcpyAsync(s->pB, s->dB, hB_n, hipMemcpyDeviceToHost, s->stream));
     BCHK(hipStreamSynchronize(s->stream));
     for (int i = 0; i < nwin; i++) {
         const BAWin &w = wins[i];
-        memcpy(res[i].poses, &hD[w.poses], (size_t)w.Nc * 7 * 8);
-        if (w.Np) memcpy(res[i].points, &hD[w.pts], (size_t)w.Np * 3 * 8);
+        memcpy(res[i].poses, &s->pD[w.poses], (size_t)w.Nc * 7 * 8);
+        if (w.Np) memcpy(res[i].points, &s->pD[w.pts], (size_t)w.Np * 3 * 8);
         if (res[i].outlier)
-            for (int k = 0; k < w.E; k++) res[i].outlier[hw[i].perm[k]] = (hB[w.flags + k] & 1) ? 0 : 1;
-        res[i].chi2_initial = hD[w.st + ST_CHI0];
-        res[i].chi2_final = hD[w.st + ST_CHI];
-        res[i].iterations = (int)hD[w.st + ST_ITERS];
-        res[i].lin_solves = (int)hD[w.st + ST_SOLVES];
+            for (int k = 0; k < w.E; k++) res[i].outlier[hw[i].perm[k]] = (s->pB[w.flags + k] & 1) ? 0 : 1;
+        res[i].chi2_initial = s->pD[w.st + ST_CHI0];
+        res[i].chi2_final = s->pD[w.st + ST_CHI];
+        res[i].iterations = (int)s->pD[w.st + ST_ITERS];
+        res[i].lin_solves = (int)s->pD[w.st + ST_SOLVES];
     }
     if (prof) {
         double pcg = 0;
-        for (int i = 0; i < nwin; i++) pcg += hD[wins[i].st + ST_PCG_ITERS];
+        for (int i = 0; i < nwin; i++) pcg += s->pD[wins[i].st + ST_PCG_ITERS];
         fprintf(stderr, "[ba] %d windows: stage+upload %.2f ms, device %.2f ms, download %.2f ms, D %.1f MB, I %.1f MB, pcg its/window %.0f\n",
                 nwin, (t_staged - t_start) * 1e3, (t_solved - t_staged) * 1e3, (tnow() - t_solved) * 1e3,
-                (hD.size() + scratchD) * 8e-6, hI.size() * 4e-6, pcg / nwin);
+                (hD_n + scratchD) * 8e-6, hI_n * 4e-6, pcg / nwin);
     }
     return ORB_OK;
 }
