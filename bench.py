@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=512, help="frames per GPU per step")
     ap.add_argument("--cpu-frames", type=int, default=48, help="CPU baseline sample size (0 = skip)")
-    ap.add_argument("--ba-windows", type=int, default=64, help="windows in the local-BA side measurement (0 = skip)")
+    ap.add_argument("--ba-windows", type=int, default=256, help="windows in the local-BA side measurement (0 = skip)")
     args = ap.parse_args()
 
     import torch
