@@ -62,7 +62,9 @@ struct BAWin {
     int64_t flags; /* per edge: bit0 active, bit1 robust */
 };
 /* LM state (doubles at D[st + i]) */
-enum { ST_LAMBDA = 0, ST_NI, ST_CHI, ST_CHI0, ST_ITERS, ST_SOLVES, ST_TERM, ST_ROUND_IT, ST_HAVE_CHI0, ST_PCG_ITERS, ST_COUNT };
+enum { ST_LAMBDA = 0, ST_NI, ST_CHI, ST_CHI0, ST_ITERS, ST_SOLVES, ST_TERM, ST_ROUND_IT, ST_HAVE_CHI0, ST_PCG_ITERS,
+       ST_T0, /* 10 phase timers (profile mode), 100 MHz ticks */
+       ST_COUNT = ST_T0 + 10 };
 
 struct BABufs {
     double *D;
@@ -255,6 +257,17 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (st[ST_TERM] != 0.0) return; /* uniform: this window's round already terminated */
     const int n = w.Ncf * 6;
+    /* profile mode: thread 0 accumulates wall time per phase (diagnostic build path only, never in timed runs) */
+    unsigned long long t_prev = debug ? __builtin_amdgcn_s_memrealtime() : 0ull;
+#define BA_STAMP(slot)                                                        \
+    if (debug) {                                                              \
+        __syncthreads();                                                      \
+        if (tid == 0) {                                                       \
+            const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); \
+            st[ST_T0 + (slot)] += (double)(t_now - t_prev);                   \
+            t_prev = t_now;                                                   \
+        }                                                                     \
+    }
 
     /* ---- computeActiveErrors + activeRobustChi2 ---- */
     double currentChi = eval_chi2(w, D, I, B, w.poses, w.pts, w.err, s);
@@ -264,6 +277,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
     }
     __syncthreads();
 
+    BA_STAMP(0)
     /* ---- buildSystem: Hll, bl, W (thread per point) ---- */
     for (int p = tid; p < w.Np; p += BA_T) {
         double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
@@ -306,6 +320,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
         for (int i = 0; i < 9; i++) D[w.Hll + (int64_t)p * 9 + i] = H[i];
         for (int i = 0; i < 3; i++) D[w.bl + (int64_t)p * 3 + i] = b[i];
     }
+    BA_STAMP(1)
     /* ---- Hpp, bp: one wavefront per free camera, lanes over its edges, shuffle reduction ---- */
     for (int c = wave; c < w.Nc; c += BA_W) {
         const int sl = I[w.slot + c];
@@ -359,6 +374,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
     }
     __syncthreads();
 
+    BA_STAMP(2)
     /* ---- computeLambdaInit on the first iteration of an optimize() call ---- */
     double lambda = st[ST_LAMBDA], ni = st[ST_NI];
     if (first_of_round) {
@@ -395,53 +411,69 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
             Iv[7] = (Dm[1] * Dm[6] - Dm[0] * Dm[7]) * id;
             Iv[8] = (Dm[0] * Dm[4] - Dm[1] * Dm[3]) * id;
             for (int i = 0; i < 9; i++) D[w.Dinv + (int64_t)p * 9 + i] = Iv[i];
-            const int e0 = I[w.pt_start + p], e1 = I[w.pt_start + p + 1];
-            for (int e = e0; e < e1; e++) {
-                const double *We = D + w.W + (int64_t)e * 18;
-                double *Ye = D + w.Y + (int64_t)e * 18;
-                for (int a = 0; a < 6; a++)
-                    for (int bb = 0; bb < 3; bb++)
-                        Ye[a * 3 + bb] = We[a * 3] * Iv[bb] + We[a * 3 + 1] * Iv[3 + bb] + We[a * 3 + 2] * Iv[6 + bb];
-            }
         }
         __syncthreads();
+        /* Y = W Dinv, one thread per (edge, row of W): neighbouring threads touch neighbouring 24-B rows */
+        for (int t = tid; t < w.E * 6; t += BA_T) {
+            const int e = t / 6, a = t - e * 6;
+            const double *Wr = D + w.W + (int64_t)e * 18 + a * 3;
+            const double *Iv = D + w.Dinv + (int64_t)I[w.pt + e] * 9;
+            const double w0 = Wr[0], w1 = Wr[1], w2 = Wr[2];
+            double *Yr = D + w.Y + (int64_t)e * 18 + a * 3;
+            Yr[0] = w0 * Iv[0] + w1 * Iv[3] + w2 * Iv[6];
+            Yr[1] = w0 * Iv[1] + w1 * Iv[4] + w2 * Iv[7];
+            Yr[2] = w0 * Iv[2] + w1 * Iv[5] + w2 * Iv[8];
+        }
+        __syncthreads();
+        BA_STAMP(3)
         /* ---- S = Hpp + lambda I - sum Y W^T : one wavefront per non-zero 6x6 block.  Each LANE takes whole
            contributions (stride 64: 64 independent Y/W gathers in flight), accumulates its own 6x6 partial in
            registers, and the 36 partials are summed across the wavefront with shuffles -- fixed order, no
            atomics. ---- */
-        for (int bk = wave; bk < w.nnzb; bk += BA_W) {
-            const int k0 = I[w.con_start + bk], k1 = I[w.con_start + bk + 1];
+        /* four blocks per wavefront: 16 lanes per block (16 independent Y/W gathers in flight per block, 64 per
+           wave), so the per-block reduction is a 4-step butterfly inside a 16-lane row instead of 6 steps over
+           the whole wave */
+        for (int bk0 = wave * 4; bk0 < w.nnzb; bk0 += BA_W * 4) {
+            const int sub = lane >> 4, l16 = lane & 15;
+            const int bk = bk0 + sub;
             double acc[36];
 #pragma unroll
             for (int i = 0; i < 36; i++) acc[i] = 0.0;
-            for (int k = k0 + lane; k < k1; k += 64) {
-                const double *Y1 = D + w.Y + (int64_t)I[w.con_e1 + k] * 18;
-                const double *W2 = D + w.W + (int64_t)I[w.con_e2 + k] * 18;
-                double y[18], ww[18];
+            if (bk < w.nnzb) {
+                const int k0 = I[w.con_start + bk], k1 = I[w.con_start + bk + 1];
+                for (int k = k0 + l16; k < k1; k += 16) {
+                    const double2 *Y1 = (const double2 *)(D + w.Y + (int64_t)I[w.con_e1 + k] * 18); /* 144-B records */
+                    const double2 *W2 = (const double2 *)(D + w.W + (int64_t)I[w.con_e2 + k] * 18);
+                    double y[18], ww[18];
 #pragma unroll
-                for (int i = 0; i < 18; i++) {
-                    y[i] = Y1[i];
-                    ww[i] = W2[i];
+                    for (int i = 0; i < 9; i++) {
+                        const double2 a2 = Y1[i], b2 = W2[i];
+                        y[2 * i] = a2.x;
+                        y[2 * i + 1] = a2.y;
+                        ww[2 * i] = b2.x;
+                        ww[2 * i + 1] = b2.y;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 6; r++)
+#pragma unroll
+                        for (int c = 0; c < 6; c++)
+                            acc[r * 6 + c] += y[r * 3] * ww[c * 3] + y[r * 3 + 1] * ww[c * 3 + 1] + y[r * 3 + 2] * ww[c * 3 + 2];
                 }
-#pragma unroll
-                for (int r = 0; r < 6; r++)
-#pragma unroll
-                    for (int c = 0; c < 6; c++)
-                        acc[r * 6 + c] += y[r * 3] * ww[c * 3] + y[r * 3 + 1] * ww[c * 3 + 1] + y[r * 3 + 2] * ww[c * 3 + 2];
             }
 #pragma unroll
             for (int i = 0; i < 36; i++) {
                 double v = acc[i];
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
                 acc[i] = v;
             }
-            if (lane == 0) {
+            if (l16 == 0 && bk < w.nnzb) {
 #pragma unroll
                 for (int i = 0; i < 36; i++) D[w.S + (int64_t)bk * 36 + i] = -acc[i];
             }
         }
         __syncthreads();
+        BA_STAMP(4)
         /* diagonal blocks: + Hpp + lambda I ; g = bp - sum_e Y_e bl  (thread per reduced row) */
         for (int i = tid; i < n; i += BA_T) {
             const int sl = i / 6, a = i % 6;
@@ -462,6 +494,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
             D[w.g + i] = gv;
         }
         __syncthreads();
+        BA_STAMP(5)
         /* ---- block-Jacobi preconditioner: inverse of the 6x6 diagonal blocks (thread per camera) ---- */
         bool ok_local = true;
         for (int sl = tid; sl < w.Ncf; sl += BA_T) {
@@ -502,6 +535,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
                     Mi[i * 6 + j] = v;
                 }
         }
+        BA_STAMP(6)
         /* ---- PCG on S x = g ---- */
         double xi[3] = {0, 0, 0}, ri[3], zi[3], pi[3]; /* each thread owns rows tid, tid+BA_T, tid+2*BA_T */
         double rz_loc = 0, gg_loc = 0;
@@ -600,6 +634,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
             if (i < n) D[w.x + i] = ok2 ? xi[q] : 0.0;
         }
         __syncthreads();
+        BA_STAMP(7)
         /* ---- back-substitution: xl = Dinv (bl - sum_e W_e^T x_c) (thread per point) + trial update ---- */
         double scale_loc = 0;
         for (int p = tid; p < w.Np; p += BA_T) {
@@ -634,6 +669,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
             }
         }
         __syncthreads();
+        BA_STAMP(8)
         double tempChi = eval_chi2(w, D, I, B, w.poses_t, w.pts_t, w.err_t, s);
         if (!ok2) tempChi = 1.7976931348623157e308;
         double scale = block_sum(scale_loc, s);
@@ -654,7 +690,8 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
             ni *= 2;
         }
         qmax++;
-        if (debug && tid == 0)
+        BA_STAMP(9)
+        if (debug > 1 && tid == 0)
             printf("[dev] win %d trial %d ok %d pcg %d cur %.10e temp %.10e rho %.6e lambda %.6e\n", (int)blockIdx.x, qmax,
                    (int)ok2, it, currentChi, tempChi, rho, lambda);
         __syncthreads();
@@ -1100,7 +1137,7 @@ extern "C" int ba_solve_batch(BASolver *s, const BAProblem *probs, BAResult *res
                 break;
             }
             hipLaunchKernelGGL(k_ba_iteration, dim3(nwin), dim3(BA_T), 0, s->stream, bufs, it == 0 ? 1 : 0, s->pcg_tol2,
-                               pcg_maxit, getenv("ORBSLAM_AMD_BA_DEBUG") ? 1 : 0);
+                               pcg_maxit, getenv("ORBSLAM_AMD_BA_DEBUG") ? 2 : (prof ? 1 : 0));
             BCHK(hipGetLastError());
             /* the stop flag must be observed between iterations, as the reference's optimizer would */
             bool any_stop_ptr = false;
@@ -1145,6 +1182,11 @@ extern "C" int ba_solve_batch(BASolver *s, const BAProblem *probs, BAResult *res
         fprintf(stderr, "[ba] %d windows: stage+upload %.2f ms, device %.2f ms, download %.2f ms, D %.1f MB, I %.1f MB, pcg its/window %.0f\n",
                 nwin, (t_staged - t_start) * 1e3, (t_solved - t_staged) * 1e3, (tnow() - t_solved) * 1e3,
                 (hD_n + scratchD) * 8e-6, hI_n * 4e-6, pcg / nwin);
+        static const char *names[10] = {"chi2", "Hll+W", "Hpp", "Dinv+Y(+lambda0)", "Schur", "g+diag", "Minv", "PCG",
+                                        "backsub+update", "trial chi2+decision"};
+        fprintf(stderr, "[ba] window 0 phase ms:");
+        for (int k = 0; k < 10; k++) fprintf(stderr, " %s %.2f |", names[k], s->pD[wins[0].st + ST_T0 + k] * 1e-5);
+        fprintf(stderr, "\n");
     }
     return ORB_OK;
 }
