@@ -91,6 +91,14 @@ struct OrbExtractor {
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool overlap = true;
+    /* HIP graph of the whole host-pointer call (H2D, 12 kernels incl. the fork/join, 3 x D2H): captured on the
+       second call with the same (w, h, n_frames) and replayed afterwards -- one launch instead of 16 */
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    long graph_gen = -1;       /* value of `generation` the graph was captured at */
+    int graph_w = 0, graph_h = 0, graph_n = 0, graph_seen = 0;
+    long generation = 0;       /* bumped whenever a device / staging buffer or the geometry changes */
+    bool use_graph = true;
 };
 
 /* reference src/ORBextractor.cpp:360-420 */
@@ -280,8 +288,10 @@ static int build_geom(OrbExtractor *h, int w, int hgt) {
     return ORB_OK;
 }
 
+static long *g_generation_sink = nullptr; /* set by the caller of grow() */
 template <typename T> static int grow(T *&p, size_t &cap, size_t need) {
     if (need <= cap && p) return ORB_OK;
+    if (g_generation_sink) (*g_generation_sink)++;
     if (p) HIPCHK(hipFree(p));
     p = nullptr;
     cap = 0;
@@ -291,6 +301,7 @@ template <typename T> static int grow(T *&p, size_t &cap, size_t need) {
 }
 
 static int ensure_buffers(OrbExtractor *h, int n_frames) {
+    g_generation_sink = &h->generation;
     const OrbGeom &g = h->geom;
     const size_t F = (size_t)std::max(n_frames, h->max_batch);
     int rc;
@@ -309,6 +320,8 @@ static int ensure_buffers(OrbExtractor *h, int n_frames) {
 static int set_geometry(OrbExtractor *h, int w, int hgt) {
     if (h->geom_valid && h->geom.w == w && h->geom.h == hgt) return ORB_OK;
     h->geom_valid = false;
+    h->generation++;
+    g_generation_sink = &h->generation;
     int rc = build_geom(h, w, hgt);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(h->stream)); /* previous launches may still read the old tables */
@@ -348,6 +361,7 @@ extern "C" int orb_max_keypoints(const OrbExtractor *h);
 /* pinned + device staging of the host-pointer API, sized for batch frames of w x hgt */
 static int alloc_staging(OrbExtractor *h, int w, int hgt, int batch) {
     free_staging(h);
+    h->generation++;
     h->out_cap = orb_max_keypoints(h);
     const size_t in_bytes = (size_t)batch * align_up(w, 64) * hgt;
     h->cap_in = in_bytes;
@@ -413,6 +427,7 @@ extern "C" int orb_create(const OrbConfig *cfg, int max_w, int max_h, int max_ba
         return fail(ORB_E_HIP);
     }
     h->overlap = getenv("ORBSLAM_AMD_NO_OVERLAP") == nullptr;
+    h->use_graph = getenv("ORBSLAM_AMD_NO_GRAPH") == nullptr;
     if (orb_upload_constants() != hipSuccess) {
         g_err = "constant upload failed";
         return fail(ORB_E_HIP);
@@ -440,6 +455,8 @@ extern "C" void orb_destroy(OrbExtractor *h) {
     (void)hipFree(h->d_cells);
     (void)hipFree(h->d_tab_i);
     (void)hipFree(h->d_tab_c);
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    if (h->graph) (void)hipGraphDestroy(h->graph);
     free_staging(h);
     for (int r = 0; r < OrbExtractor::kProfRing; r++)
         for (int i = 0; i < 8; i++)
@@ -599,14 +616,60 @@ extern "C" int orb_extract_batch(OrbExtractor *h, const uint8_t *const *imgs, in
         }
         for (int y = 0; y < hgt; y++) memcpy(h->h_in + f * fbytes + (size_t)y * pitch, imgs[f] + (size_t)y * stride, w);
     }
-    HIPCHK(hipMemcpyAsync(h->d_in, h->h_in, fbytes * n_frames, hipMemcpyHostToDevice, h->stream));
-    rc = orb_extract_batch_device(h, h->d_in, n_frames, w, hgt, pitch, (int64_t)fbytes, h->d_kps, h->d_desc, h->out_cap,
-                                  h->d_counts, h->stream);
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(h->h_counts, h->d_counts, (size_t)n_frames * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(h->h_kps, h->d_kps, (size_t)n_frames * h->out_cap * sizeof(OrbKeyPoint), hipMemcpyDeviceToHost,
-                          h->stream));
-    HIPCHK(hipMemcpyAsync(h->h_desc, h->d_desc, (size_t)n_frames * h->out_cap * 32, hipMemcpyDeviceToHost, h->stream));
+    if ((rc = ensure_buffers(h, n_frames))) return rc;
+    auto enqueue = [&]() -> int {
+        HIPCHK(hipMemcpyAsync(h->d_in, h->h_in, fbytes * n_frames, hipMemcpyHostToDevice, h->stream));
+        int r = orb_extract_batch_device(h, h->d_in, n_frames, w, hgt, pitch, (int64_t)fbytes, h->d_kps, h->d_desc,
+                                         h->out_cap, h->d_counts, h->stream);
+        if (r) return r;
+        HIPCHK(hipMemcpyAsync(h->h_counts, h->d_counts, (size_t)n_frames * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(h->h_kps, h->d_kps, (size_t)n_frames * h->out_cap * sizeof(OrbKeyPoint), hipMemcpyDeviceToHost,
+                              h->stream));
+        HIPCHK(hipMemcpyAsync(h->h_desc, h->d_desc, (size_t)n_frames * h->out_cap * 32, hipMemcpyDeviceToHost, h->stream));
+        return ORB_OK;
+    };
+    /* graphs pay off where launch overhead dominates (a few frames per call); big batches stay eager */
+    const bool want_graph = h->use_graph && !h->profile && n_frames <= 8;
+    const bool same = h->graph_exec && h->graph_gen == h->generation && h->graph_w == w && h->graph_h == hgt &&
+                      h->graph_n == n_frames;
+    if (want_graph && same) {
+        HIPCHK(hipGraphLaunch(h->graph_exec, h->stream)); /* replay */
+        h->last_frames = n_frames;
+    } else if (want_graph && h->graph_seen && h->graph_gen == h->generation && h->graph_w == w &&
+               h->graph_h == hgt && h->graph_n == n_frames) {
+        /* second call with this shape (the first ran eagerly and did every one-time setup): capture */
+        if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+        if (h->graph) (void)hipGraphDestroy(h->graph);
+        h->graph_exec = nullptr;
+        h->graph = nullptr;
+        HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        rc = enqueue();
+        hipError_t ce = hipStreamEndCapture(h->stream, &h->graph);
+        if (rc || ce != hipSuccess || hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0) != hipSuccess) {
+            /* capture not possible here: fall back to eager launches for good (still the same kernels) */
+            h->use_graph = false;
+            if (h->graph) (void)hipGraphDestroy(h->graph);
+            h->graph = nullptr;
+            h->graph_exec = nullptr;
+            if ((rc = enqueue())) return rc;
+        } else {
+            HIPCHK(hipGraphLaunch(h->graph_exec, h->stream));
+            h->last_frames = n_frames;
+        }
+    } else {
+        if ((rc = enqueue())) return rc;
+        h->graph_seen = 1;
+        h->graph_gen = h->generation;
+        h->graph_w = w;
+        h->graph_h = hgt;
+        h->graph_n = n_frames;
+        if (h->graph_exec) { /* shape changed: drop the stale graph */
+            (void)hipGraphExecDestroy(h->graph_exec);
+            (void)hipGraphDestroy(h->graph);
+            h->graph_exec = nullptr;
+            h->graph = nullptr;
+        }
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
     int worst = ORB_OK;
     for (int f = 0; f < n_frames; f++) {
