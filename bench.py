@@ -107,14 +107,21 @@ def ba_throughput(device, n_windows):
 
 
 def main():
+    global W, H, NFEATURES
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=512, help="frames per GPU per step")
     ap.add_argument("--cpu-frames", type=int, default=48, help="CPU baseline sample size (0 = skip)")
+    ap.add_argument("--size", default="640x480", help="frame size WxH (configs[1] = 640x480; 1280x720 = configs[3] shape)")
+    ap.add_argument("--window", type=int, default=-1, help="match window (-1 = brute force; 100 = the reference's "
+                    "SearchForInitialization call, src/Tracking.cpp:189)")
+    ap.add_argument("--nfeatures", type=int, default=NFEATURES)
     ap.add_argument("--ba-windows", type=int, default=256, help="windows in the local-BA side measurement (0 = skip)")
     args = ap.parse_args()
+    W, H = (int(v) for v in args.size.lower().split("x"))
+    NFEATURES = args.nfeatures
 
     import torch
     import torch.distributed as dist
@@ -205,7 +212,7 @@ def main():
         with torch.cuda.stream(sB):
             sB.wait_event(sl.extracted)
             matcher.match_batch_device(sl.kps.data_ptr(), sl.desc.data_ptr(), sl.cnt.data_ptr(), cap, pa.data_ptr(),
-                                       pb.data_ptr(), B, bounds, -1, sl.m12.data_ptr(), sl.nm.data_ptr(), pB)
+                                       pb.data_ptr(), B, bounds, args.window, sl.m12.data_ptr(), sl.nm.data_ptr(), pB)
             sl.matched.record(sB)
 
     def barrier():
@@ -258,13 +265,16 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "frames/s ORB extract+match @640x480", "value": round(fps, 2), "unit": "frames/s",
+            "metric": "frames/s ORB extract+match @%dx%d" % (W, H), "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "rehearsal": rehearse,
-            "config": {"workload": "configs[1]: ORB extract (8 levels, 1000 features, FAST 20/7) + brute-force "
-                                   "Hamming match of consecutive frames, 640x480 stream",
+            "config": {"workload": "%s: ORB extract (8 levels, %d features, FAST 20/7) + %s match of consecutive "
+                                   "frames, %dx%d stream" % ("configs[1]" if (W, H, args.window) == (640, 480, -1) else
+                                                             "variant", NFEATURES,
+                                                             "brute-force Hamming" if args.window < 0 else
+                                                             "SearchForInitialization(window=%d)" % args.window, W, H),
                        "frames_per_gpu_per_step": B, "pairs_per_gpu_per_step": B,
                        "keypoints_per_frame": round(n_kp, 1), "matches_per_pair": round(float(nmatch.mean()), 1),
                        "exchange": "rccl all_gather of kp/desc/count slabs" if world > 1 else "none"},
