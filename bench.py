@@ -204,13 +204,15 @@ def main():
             sA.wait_event(sl.matched)  # the match that last read this slab has finished
             ext.extract_batch_device(d_imgs.data_ptr(), B, W, H, W, W * H, sl.k_loc.data_ptr(), sl.d_loc.data_ptr(), cap,
                                      sl.c_loc.data_ptr(), pA)
-            if world > 1:  # the one exchange step of the path: fixed-capacity feature slabs over xGMI
-                all_gather_flat(sl.kps, sl.k_loc)
-                all_gather_flat(sl.desc, sl.d_loc)
-                all_gather_flat(sl.cnt, sl.c_loc)
             sl.extracted.record(sA)
         with torch.cuda.stream(sB):
             sB.wait_event(sl.extracted)
+            if world > 1:
+                # the one exchange step of the path: fixed-capacity feature slabs over xGMI (RCCL all-gather).  It
+                # lives on the MATCH stream, so the next batch's extraction (stream A) overlaps it.
+                all_gather_flat(sl.kps, sl.k_loc)
+                all_gather_flat(sl.desc, sl.d_loc)
+                all_gather_flat(sl.cnt, sl.c_loc)
             matcher.match_batch_device(sl.kps.data_ptr(), sl.desc.data_ptr(), sl.cnt.data_ptr(), cap, pa.data_ptr(),
                                        pb.data_ptr(), B, bounds, args.window, sl.m12.data_ptr(), sl.nm.data_ptr(), pB)
             sl.matched.record(sB)
