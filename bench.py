@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--window", type=int, default=-1, help="match window (-1 = brute force; 100 = the reference's "
                     "SearchForInitialization call, src/Tracking.cpp:189)")
     ap.add_argument("--nfeatures", type=int, default=NFEATURES)
+    ap.add_argument("--split", type=int, default=2, help="1 or 2: halves of a batch on separate stream pairs")
     ap.add_argument("--ba-windows", type=int, default=256, help="windows in the local-BA side measurement (0 = skip)")
     args = ap.parse_args()
     W, H = (int(v) for v in args.size.lower().split("x"))
@@ -162,6 +163,14 @@ def main():
                           device=local_rank)
     cap = ext.cap
     matcher = oa.ORBmatcher(0.9, True, max_keypoints=cap, max_pairs=B, device=local_rank)
+    # a second extractor/matcher pair lets the two HALVES of a step's batch run on their own streams: the
+    # latency-bound stages of one half (quadtree, match resolution) then overlap the throughput-bound stages of
+    # the other (pyramid, FAST, blur)
+    nsplit = max(1, min(args.split, 2))
+    ext2 = matcher2 = None
+    if nsplit == 2:
+        ext2 = oa.ORBextractor(NFEATURES, SCALE, NLEVELS, INI_TH, MIN_TH, max_w=W, max_h=H, max_batch=B, device=local_rank)
+        matcher2 = oa.ORBmatcher(0.9, True, max_keypoints=cap, max_pairs=B, device=local_rank)
 
     frames = synth.make_stream(1000 + rank, B, W, H)
     d_imgs = torch.from_numpy(frames).to(dev)
@@ -192,30 +201,49 @@ def main():
             self.matched = torch.cuda.Event()
 
     slabs = [Slab(), Slab()]
-    sA = torch.cuda.Stream(device=dev)
-    sB = torch.cuda.Stream(device=dev)
-    pA, pB = C.c_void_p(sA.cuda_stream), C.c_void_p(sB.cuda_stream)
+    if world > 1:
+        nsplit = 1  # the exchange orders the two halves anyway
+    exts = [ext, ext2][:nsplit]
+    matchers = [matcher, matcher2][:nsplit]
+    sAs = [torch.cuda.Stream(device=dev) for _ in range(nsplit)]
+    sBs = [torch.cuda.Stream(device=dev) for _ in range(nsplit)]
+    for sl in slabs:
+        sl.extracted = [torch.cuda.Event() for _ in range(nsplit)]
+        sl.matched = [torch.cuda.Event() for _ in range(nsplit)]
+    Bh = B // nsplit  # frames per launch
+    assert Bh * nsplit == B
     step_no = [0]
 
     def step():
         sl = slabs[step_no[0] & 1]
         step_no[0] += 1
-        with torch.cuda.stream(sA):
-            sA.wait_event(sl.matched)  # the match that last read this slab has finished
-            ext.extract_batch_device(d_imgs.data_ptr(), B, W, H, W, W * H, sl.k_loc.data_ptr(), sl.d_loc.data_ptr(), cap,
-                                     sl.c_loc.data_ptr(), pA)
-            sl.extracted.record(sA)
-        with torch.cuda.stream(sB):
-            sB.wait_event(sl.extracted)
-            if world > 1:
-                # the one exchange step of the path: fixed-capacity feature slabs over xGMI (RCCL all-gather).  It
-                # lives on the MATCH stream, so the next batch's extraction (stream A) overlaps it.
-                all_gather_flat(sl.kps, sl.k_loc)
-                all_gather_flat(sl.desc, sl.d_loc)
-                all_gather_flat(sl.cnt, sl.c_loc)
-            matcher.match_batch_device(sl.kps.data_ptr(), sl.desc.data_ptr(), sl.cnt.data_ptr(), cap, pa.data_ptr(),
-                                       pb.data_ptr(), B, bounds, args.window, sl.m12.data_ptr(), sl.nm.data_ptr(), pB)
-            sl.matched.record(sB)
+        for hh in range(nsplit):
+            sA = sAs[hh]
+            with torch.cuda.stream(sA):
+                for ev in sl.matched:
+                    sA.wait_event(ev)  # the matches that last read this slab have finished
+                f0 = hh * Bh
+                exts[hh].extract_batch_device(d_imgs.data_ptr() + f0 * W * H, Bh, W, H, W, W * H,
+                                              sl.k_loc.data_ptr() + f0 * cap * 28, sl.d_loc.data_ptr() + f0 * cap * 32, cap,
+                                              sl.c_loc.data_ptr() + f0 * 4, C.c_void_p(sA.cuda_stream))
+                sl.extracted[hh].record(sA)
+        for hh in range(nsplit):
+            sB = sBs[hh]
+            with torch.cuda.stream(sB):
+                for ev in sl.extracted:
+                    sB.wait_event(ev)  # pair (k, k+1) may straddle the halves
+                if world > 1:
+                    # the one exchange step of the path: fixed-capacity feature slabs over xGMI (RCCL all-gather).
+                    # It lives on the MATCH stream, so the next batch's extraction (stream A) overlaps it.
+                    all_gather_flat(sl.kps, sl.k_loc)
+                    all_gather_flat(sl.desc, sl.d_loc)
+                    all_gather_flat(sl.cnt, sl.c_loc)
+                p0 = hh * Bh
+                matchers[hh].match_batch_device(sl.kps.data_ptr(), sl.desc.data_ptr(), sl.cnt.data_ptr(), cap,
+                                                pa.data_ptr() + p0 * 4, pb.data_ptr() + p0 * 4, Bh, bounds, args.window,
+                                                sl.m12.data_ptr() + p0 * cap * 4, sl.nm.data_ptr() + p0 * 4,
+                                                C.c_void_p(sB.cuda_stream))
+                sl.matched[hh].record(sB)
 
     def barrier():
         torch.cuda.synchronize()
@@ -256,14 +284,14 @@ def main():
         ab = algorithmic_bytes_per_frame(ext.level_sizes(W, H), n_kp)
         timed = {k: v for k, v in stage_ms.items() if ab.get(k, 0) > 0}
         dom = max(timed, key=timed.get)
-        achieved = ab[dom] * B / (stage_ms[dom] * 1e-3) / 1e9
+        achieved = ab[dom] * Bh / (stage_ms[dom] * 1e-3) / 1e9  # one launch covers Bh frames
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if dom in tj:  # collected per launch at tj['_batch'] frames; per-frame traffic is batch independent
-                    traffic = int(tj[dom] * B / float(tj.get("_batch", B)))
+                    traffic = int(tj[dom] * Bh / float(tj.get("_batch", Bh)))
             except Exception:
                 traffic = None
         out = {
@@ -277,12 +305,12 @@ def main():
                                                              "variant", NFEATURES,
                                                              "brute-force Hamming" if args.window < 0 else
                                                              "SearchForInitialization(window=%d)" % args.window, W, H),
-                       "frames_per_gpu_per_step": B, "pairs_per_gpu_per_step": B,
+                       "frames_per_gpu_per_step": B, "pairs_per_gpu_per_step": B, "launch_lanes": nsplit,
                        "keypoints_per_frame": round(n_kp, 1), "matches_per_pair": round(float(nmatch.mean()), 1),
                        "exchange": "rccl all_gather of kp/desc/count slabs" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(ab[dom] * B),
+                         "algorithmic_bytes_per_launch": int(ab[dom] * Bh), "frames_per_launch": Bh,
                          "avg_launch_ms": round(stage_ms[dom], 4)},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
         }
