@@ -877,58 +877,52 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hD, size_t &sc
         std::vector<int> cp(cstart.begin(), cstart.end() - 1);
         for (int k = 0; k < E; k++) cedges[cp[p->cam_idx[hw.perm[k]]]++] = k;
     }
-    /* reduced-system block structure + contribution lists */
-    std::vector<std::vector<int>> rowcols(Ncf);
-    for (int sl = 0; sl < Ncf; sl++) rowcols[sl].push_back(sl); /* diagonal always present */
+    /* reduced-system block structure + contribution lists.  A dense Ncf x Ncf table maps a camera-slot pair to its
+       block id (counts first, ids after a row-major sweep), so the O(sum k^2) passes over the co-observation pairs
+       are plain table look-ups: no per-row vectors, no sorting, no binary searches. */
+    std::vector<int> eslot(E); /* camera slot of every (sorted) edge, -1 = fixed camera */
+    for (int k = 0; k < E; k++) eslot[k] = slot[p->cam_idx[hw.perm[k]]];
+    std::vector<int> blk((size_t)Ncf * Ncf, 0); /* pass 1: contributions per pair; pass 2: block id */
     for (int pt = 0; pt < Np; pt++)
         for (int a = cnt[pt]; a < cnt[pt + 1]; a++) {
-            const int s1 = slot[p->cam_idx[hw.perm[a]]];
+            const int s1 = eslot[a];
             if (s1 < 0) continue;
+            int *row = &blk[(size_t)s1 * Ncf];
             for (int b = cnt[pt]; b < cnt[pt + 1]; b++) {
-                const int s2 = slot[p->cam_idx[hw.perm[b]]];
-                if (s2 >= 0) rowcols[s1].push_back(s2);
+                const int s2 = eslot[b];
+                if (s2 >= 0) row[s2]++;
             }
         }
-    std::vector<int> brow(Ncf + 1, 0), bcol, bdiag(Ncf, 0);
-    for (int sl = 0; sl < Ncf; sl++) {
-        auto &v = rowcols[sl];
-        std::sort(v.begin(), v.end());
-        v.erase(std::unique(v.begin(), v.end()), v.end());
-        brow[sl + 1] = brow[sl] + (int)v.size();
-        for (int c : v) {
-            if (c == sl) bdiag[sl] = (int)bcol.size();
-            bcol.push_back(c);
+    std::vector<int> brow(Ncf + 1, 0), bcol, bdiag(Ncf, 0), ccount(1, 0);
+    for (int s1 = 0; s1 < Ncf; s1++) {
+        int *row = &blk[(size_t)s1 * Ncf];
+        for (int s2 = 0; s2 < Ncf; s2++) {
+            const int nc = row[s2];
+            if (nc > 0 || s2 == s1) { /* the diagonal block always exists (Hpp + lambda I) */
+                if (s2 == s1) bdiag[s1] = (int)bcol.size();
+                row[s2] = (int)bcol.size();
+                bcol.push_back(s2);
+                ccount.push_back(ccount.back() + nc);
+            } else
+                row[s2] = -1;
         }
+        brow[s1 + 1] = (int)bcol.size();
     }
     const int nnzb = (int)bcol.size();
     w.nnzb = nnzb;
-    auto block_of = [&](int s1, int s2) {
-        const auto &v = rowcols[s1];
-        return brow[s1] + (int)(std::lower_bound(v.begin(), v.end(), s2) - v.begin());
-    };
-    std::vector<int> ccount(nnzb + 1, 0);
-    for (int pt = 0; pt < Np; pt++)
-        for (int a = cnt[pt]; a < cnt[pt + 1]; a++) {
-            const int s1 = slot[p->cam_idx[hw.perm[a]]];
-            if (s1 < 0) continue;
-            for (int b = cnt[pt]; b < cnt[pt + 1]; b++) {
-                const int s2 = slot[p->cam_idx[hw.perm[b]]];
-                if (s2 >= 0) ccount[block_of(s1, s2) + 1]++;
-            }
-        }
-    for (int i = 0; i < nnzb; i++) ccount[i + 1] += ccount[i];
     const int ncon = ccount[nnzb];
     std::vector<int> ce1(ncon), ce2(ncon);
     {
         std::vector<int> cp(ccount.begin(), ccount.end() - 1);
         for (int pt = 0; pt < Np; pt++)
             for (int a = cnt[pt]; a < cnt[pt + 1]; a++) {
-                const int s1 = slot[p->cam_idx[hw.perm[a]]];
+                const int s1 = eslot[a];
                 if (s1 < 0) continue;
+                const int *row = &blk[(size_t)s1 * Ncf];
                 for (int b = cnt[pt]; b < cnt[pt + 1]; b++) {
-                    const int s2 = slot[p->cam_idx[hw.perm[b]]];
+                    const int s2 = eslot[b];
                     if (s2 < 0) continue;
-                    const int k = cp[block_of(s1, s2)]++;
+                    const int k = cp[row[s2]]++;
                     ce1[k] = a;
                     ce2[k] = b;
                 }
