@@ -52,12 +52,12 @@ static thread_local std::string b_err;
 
 /* per-window descriptor: element offsets into the batch buffers */
 struct BAWin {
-    int Nc, Np, E, Ncf, nnzb, pad;
+    int Nc, Np, E, Ncf, nnzb, nub; /* nub: blocks on or above the diagonal */
     double fx, fy, cx, cy, delta, chi2_thr;
     /* doubles */
     int64_t poses, poses_t, pts, pts_t, obs, info, err, err_t, W, Y, Hpp, bp, Hll, bl, Dinv, S, g, Minv, x, xl, st;
     /* ints */
-    int64_t cam, pt, pt_start, cam_start, cam_edges, slot, blk_row, blk_col, blk_diag, con_start, con_e1, con_e2;
+    int64_t cam, pt, pt_start, cam_start, cam_edges, slot, blk_row, blk_col, blk_diag, blk_mirror, blk_upper, con_start, con_e1, con_e2;
     /* bytes */
     int64_t flags; /* per edge: bit0 active, bit1 robust */
 };
@@ -433,9 +433,9 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
         /* four blocks per wavefront: 16 lanes per block (16 independent Y/W gathers in flight per block, 64 per
            wave), so the per-block reduction is a 4-step butterfly inside a 16-lane row instead of 6 steps over
            the whole wave */
-        for (int bk0 = wave * 4; bk0 < w.nnzb; bk0 += BA_W * 4) {
+        for (int u0 = wave * 4; u0 < w.nub; u0 += BA_W * 4) {
             const int sub = lane >> 4, l16 = lane & 15;
-            const int bk = bk0 + sub;
+            const int bk = (u0 + sub < w.nub) ? I[w.blk_upper + u0 + sub] : w.nnzb; /* upper blocks only */
             double acc[36];
 #pragma unroll
             for (int i = 0; i < 36; i++) acc[i] = 0.0;
@@ -471,6 +471,14 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
 #pragma unroll
                 for (int i = 0; i < 36; i++) D[w.S + (int64_t)bk * 36 + i] = -acc[i];
             }
+        }
+        __syncthreads();
+        /* S is symmetric: only blocks on or above the diagonal carry contribution lists; the others are the
+           transposes of their mirrors */
+        for (int i = tid; i < w.nnzb * 36; i += BA_T) {
+            const int bk = i / 36, e = i - bk * 36;
+            const int mk = I[w.blk_mirror + bk];
+            if (mk < bk) D[w.S + i] = D[w.S + (int64_t)mk * 36 + (e % 6) * 6 + e / 6];
         }
         __syncthreads();
         BA_STAMP(4)
@@ -827,7 +835,7 @@ struct HostWin {
 static int64_t BAWin::*const kInputDFields[] = {&BAWin::poses, &BAWin::pts, &BAWin::obs, &BAWin::info, &BAWin::st};
 static int64_t BAWin::*const kIntFields[] = {&BAWin::cam,     &BAWin::pt,      &BAWin::pt_start, &BAWin::cam_start,
                                              &BAWin::cam_edges, &BAWin::slot,  &BAWin::blk_row,  &BAWin::blk_col,
-                                             &BAWin::blk_diag, &BAWin::con_start, &BAWin::con_e1, &BAWin::con_e2};
+                                             &BAWin::blk_diag, &BAWin::blk_mirror, &BAWin::blk_upper, &BAWin::con_start, &BAWin::con_e1, &BAWin::con_e2};
 static int64_t BAWin::*const kScratchFields[] = {&BAWin::poses_t, &BAWin::pts_t, &BAWin::err, &BAWin::err_t, &BAWin::W,
                                                  &BAWin::Y,       &BAWin::Hpp,   &BAWin::bp,  &BAWin::Hll,   &BAWin::bl,
                                                  &BAWin::Dinv,    &BAWin::S,     &BAWin::g,   &BAWin::Minv,  &BAWin::x,
@@ -902,7 +910,7 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hD, size_t &sc
                 if (s2 == s1) bdiag[s1] = (int)bcol.size();
                 row[s2] = (int)bcol.size();
                 bcol.push_back(s2);
-                ccount.push_back(ccount.back() + nc);
+                ccount.push_back(ccount.back() + (s2 >= s1 ? nc : 0)); /* lower blocks are mirrored, not accumulated */
             } else
                 row[s2] = -1;
         }
@@ -910,6 +918,9 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hD, size_t &sc
     }
     const int nnzb = (int)bcol.size();
     w.nnzb = nnzb;
+    std::vector<int> bmirror(nnzb); /* id of the transposed block (S is symmetric) */
+    for (int s1 = 0; s1 < Ncf; s1++)
+        for (int bk = brow[s1]; bk < brow[s1 + 1]; bk++) bmirror[bk] = blk[(size_t)bcol[bk] * Ncf + s1];
     const int ncon = ccount[nnzb];
     std::vector<int> ce1(ncon), ce2(ncon);
     {
@@ -921,7 +932,7 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hD, size_t &sc
                 const int *row = &blk[(size_t)s1 * Ncf];
                 for (int b = cnt[pt]; b < cnt[pt + 1]; b++) {
                     const int s2 = eslot[b];
-                    if (s2 < 0) continue;
+                    if (s2 < s1) continue; /* also skips fixed cameras (-1) */
                     const int k = cp[row[s2]]++;
                     ce1[k] = a;
                     ce2[k] = b;
@@ -1002,6 +1013,16 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hD, size_t &sc
     for (int i = 0; i < nnzb; i++) hI[w.blk_col + i] = bcol[i];
     w.blk_diag = allocI(Ncf);
     for (int i = 0; i < Ncf; i++) hI[w.blk_diag + i] = bdiag[i];
+    w.blk_mirror = allocI(nnzb);
+    for (int i = 0; i < nnzb; i++) hI[w.blk_mirror + i] = bmirror[i];
+    {
+        std::vector<int> upper;
+        for (int i = 0; i < nnzb; i++)
+            if (bmirror[i] >= i) upper.push_back(i);
+        w.nub = (int)upper.size();
+        w.blk_upper = allocI(upper.size());
+        for (size_t i = 0; i < upper.size(); i++) hI[w.blk_upper + i] = upper[i];
+    }
     w.con_start = allocI((size_t)nnzb + 1);
     for (int i = 0; i <= nnzb; i++) hI[w.con_start + i] = ccount[i];
     w.con_e1 = allocI(ncon);
