@@ -482,24 +482,43 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
         }
         __syncthreads();
         BA_STAMP(4)
-        /* diagonal blocks: + Hpp + lambda I ; g = bp - sum_e Y_e bl  (thread per reduced row) */
-        for (int i = tid; i < n; i += BA_T) {
-            const int sl = i / 6, a = i % 6;
-            const int bd = I[w.blk_diag + sl];
-            double *Sd = D + w.S + (int64_t)bd * 36 + a * 6;
-            for (int c = 0; c < 6; c++) Sd[c] += D[w.Hpp + (int64_t)sl * 36 + a * 6 + c];
-            Sd[a] += lambda;
-            /* g */
+        /* diagonal blocks: + Hpp + lambda I (thread per entry) */
+        for (int i = tid; i < w.Ncf * 36; i += BA_T) {
+            const int sl = i / 36, e = i - sl * 36;
+            double v = D[w.Hpp + i];
+            if (e % 7 == 0) v += lambda;
+            D[w.S + (int64_t)I[w.blk_diag + sl] * 36 + e] += v;
+        }
+        /* g = bp - sum_e Y_e bl : one wavefront per free camera, lanes over its edges (independent gathers),
+           six shuffle reductions */
+        for (int sl = wave; sl < w.Ncf; sl += BA_W) {
             const int cam = I[w.blk_row + w.Ncf + 1 + sl]; /* slot -> camera (stored behind the row starts) */
-            double gv = D[w.bp + (int64_t)sl * 6 + a];
             const int k0 = I[w.cam_start + cam], k1 = I[w.cam_start + cam + 1];
-            for (int k = k0; k < k1; k++) {
+            double acc[6] = {0, 0, 0, 0, 0, 0};
+            for (int k = k0 + lane; k < k1; k += 64) {
                 const int e = I[w.cam_edges + k];
-                const double *Ye = D + w.Y + (int64_t)e * 18 + a * 3;
+                const double2 *Ye = (const double2 *)(D + w.Y + (int64_t)e * 18);
                 const double *blp = D + w.bl + (int64_t)I[w.pt + e] * 3;
-                gv -= Ye[0] * blp[0] + Ye[1] * blp[1] + Ye[2] * blp[2];
+                const double b0 = blp[0], b1 = blp[1], b2 = blp[2];
+                double y[18];
+#pragma unroll
+                for (int i = 0; i < 9; i++) {
+                    const double2 t = Ye[i];
+                    y[2 * i] = t.x;
+                    y[2 * i + 1] = t.y;
+                }
+#pragma unroll
+                for (int a = 0; a < 6; a++) acc[a] += y[a * 3] * b0 + y[a * 3 + 1] * b1 + y[a * 3 + 2] * b2;
             }
-            D[w.g + i] = gv;
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+                double v = acc[a];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                acc[a] = v;
+            }
+            if (lane == 0)
+                for (int a = 0; a < 6; a++) D[w.g + sl * 6 + a] = D[w.bp + (int64_t)sl * 6 + a] - acc[a];
         }
         __syncthreads();
         BA_STAMP(5)
