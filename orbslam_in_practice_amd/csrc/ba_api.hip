@@ -56,8 +56,9 @@ struct BAWin {
     double fx, fy, cx, cy, delta, chi2_thr;
     /* doubles */
     int64_t poses, poses_t, pts, pts_t, obs, info, err, err_t, W, Y, Hpp, bp, Hll, bl, Dinv, S, g, Minv, x, xl, st;
+    int64_t A, Linv; /* dense reduced system (np x np) and inverse diagonal blocks of its Cholesky factor */
     /* ints */
-    int64_t cam, pt, pt_start, cam_start, cam_edges, slot, blk_row, blk_col, blk_diag, blk_mirror, blk_upper, con_start, con_e1, con_e2;
+    int64_t cam, pt, pt_start, cam_start, cam_edges, slot, blk_row, blk_col, blk_diag, blk_mirror, blk_upper, blk_rowid, con_start, con_e1, con_e2;
     /* bytes */
     int64_t flags; /* per edge: bit0 active, bit1 robust */
 };
@@ -245,10 +246,210 @@ __device__ double eval_chi2(const BAWin &w, double *D, const int32_t *I, const u
     return block_sum(acc, s);
 }
 
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Dense blocked Cholesky solve of the reduced camera system S x = g, in-kernel, one workgroup per window
+ * (what g2o's LinearSolverEigen computes with a sparse Cholesky).  Block size 16:
+ *   diagonal 16x16 block  : factorised by one wavefront in LDS (in-order LDS ops of a single wave), plus its
+ *                           inverse, so that the panel solve becomes a matrix product;
+ *   panel  L21 = A21 L11^-T and trailing update A22 -= L21 L21^T : v_mfma_f64_16x16x4_f64 (the GEMM-shaped part
+ *                           of the reduced camera system -- the one place of this code base where matrix cores
+ *                           fit), operands from an LDS-staged panel with a 17-double row pitch (bank-conflict
+ *                           free for ds_read_b64), accumulator tiles read-modify-written in global memory;
+ *   forward / backward substitution : blocked, 16 FMAs per vector element and step.
+ * f64 MFMA fragment layout (cdna_hip_programming.md section 3): A lane l holds A[l&15][k=l>>4], B lane l holds
+ * B[k=l>>4][l&15], C/D lane l register r holds C[(l>>4)+4r][l&15].
+ * Touches S about 5x less than a 320-iteration PCG does, which is what bounds the batched throughput. */
+typedef double v4d __attribute__((ext_vector_type(4)));
+#define CH_LD 17
+/* lanes of ONE wavefront exchanging data through LDS: the hardware executes a wave's LDS operations in order,
+ * the fences keep the compiler from moving this thread's loads across another lane's stores */
+#define CH_WAVE_SYNC()                                        \
+    do {                                                      \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                      \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+
+__device__ int g_chol_scalar = 0; /* debug: 1 = plain loops instead of MFMA */
+__device__ bool ba_chol_solve(const BAWin &w, double *D, const int32_t *I, int n, double *dyn, BAShared &s) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int np = (n + 15) & ~15, nb = np >> 4;
+    double *A = D + w.A;
+    double *Li = D + w.Linv;
+    double *P = dyn;                        /* panel: np x CH_LD            */
+    double *sd = P + (size_t)np * CH_LD;    /* diagonal block, 16 x CH_LD   */
+    double *sl = sd + 16 * CH_LD;           /* its inverse, 16 x CH_LD      */
+    double *z = sl + 16 * CH_LD;            /* right-hand side / solution   */
+    /* ---- assemble the dense matrix from the block-sparse S ---- */
+    for (int i = tid; i < np * np; i += BA_T) A[i] = 0.0;
+    if (tid == 0) s.bc[0] = 0.0;
+    __syncthreads();
+    for (int i = tid; i < w.nnzb * 36; i += BA_T) {
+        const int bk = i / 36, e = i - bk * 36;
+        const int r = I[w.blk_rowid + bk] * 6 + e / 6, c = I[w.blk_col + bk] * 6 + e % 6;
+        A[(int64_t)r * np + c] = D[w.S + i];
+    }
+    for (int i = n + tid; i < np; i += BA_T) A[(int64_t)i * np + i] = 1.0; /* identity padding */
+    __syncthreads();
+    /* ---- factorisation ---- */
+    for (int kb = 0; kb < nb; kb++) {
+        const int m = nb - kb - 1;
+        if (tid < 256) sd[(tid >> 4) * CH_LD + (tid & 15)] = A[(int64_t)(kb * 16 + (tid >> 4)) * np + kb * 16 + (tid & 15)];
+        __syncthreads();
+        if (wave == 0) {
+            bool bad = false;
+            for (int j = 0; j < 16; j++) {
+                double ajj = sd[j * CH_LD + j];
+                if (!(ajj > 0.0) || !isfinite(ajj)) {
+                    bad = true;
+                    ajj = 1.0;
+                }
+                const double pv = sqrt(ajj);
+                CH_WAVE_SYNC();
+                if (lane == j) sd[j * CH_LD + j] = pv;
+                if (lane > j && lane < 16) sd[lane * CH_LD + j] = sd[lane * CH_LD + j] / pv;
+                CH_WAVE_SYNC();
+                for (int e = lane; e < 256; e += 64) {
+                    const int i = e >> 4, k = e & 15;
+                    if (k > j && i >= k) sd[i * CH_LD + k] -= sd[i * CH_LD + j] * sd[k * CH_LD + j];
+                }
+                CH_WAVE_SYNC();
+            }
+            if (lane < 16) { /* column `lane` of L^-1 by forward substitution (static register indices) */
+                const int c = lane;
+                double x[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) x[i] = 0.0;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    double v = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+                    for (int k = 0; k < 16; k++)
+                        if (k < i) v -= sd[i * CH_LD + k] * x[k];
+                    x[i] = (i >= c) ? v / sd[i * CH_LD + i] : 0.0;
+                }
+#pragma unroll
+                for (int i = 0; i < 16; i++) sl[i * CH_LD + c] = x[i];
+            }
+            if (bad && lane == 0) s.bc[0] = 1.0;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            const int r = tid >> 4, c = tid & 15;
+            A[(int64_t)(kb * 16 + r) * np + kb * 16 + c] = (c <= r) ? sd[r * CH_LD + c] : 0.0;
+            Li[kb * 256 + tid] = (c <= r) ? sl[r * CH_LD + c] : 0.0;
+        }
+        /* panel: L_i = A_i * L11^-T */
+        if (g_chol_scalar) {
+            for (int e = tid; e < m * 256; e += BA_T) {
+                const int bi = e >> 8, row = (e >> 4) & 15, col = e & 15;
+                const int gi = kb + 1 + bi;
+                double v = 0;
+                for (int k = 0; k < 16; k++) v += A[(int64_t)(gi * 16 + row) * np + kb * 16 + k] * sl[col * CH_LD + k];
+                P[(bi * 16 + row) * CH_LD + col] = v;
+            }
+            __syncthreads();
+            for (int e = tid; e < m * 256; e += BA_T) {
+                const int bi = e >> 8, row = (e >> 4) & 15, col = e & 15;
+                A[(int64_t)((kb + 1 + bi) * 16 + row) * np + kb * 16 + col] = P[(bi * 16 + row) * CH_LD + col];
+            }
+        } else
+        for (int bi = wave; bi < m; bi += BA_W) {
+            const int gi = kb + 1 + bi;
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) {
+                const double a = A[(int64_t)(gi * 16 + (lane & 15)) * np + kb * 16 + 4 * s4 + (lane >> 4)];
+                const double b = (4 * s4 + (lane >> 4) <= (lane & 15)) ? sl[(lane & 15) * CH_LD + 4 * s4 + (lane >> 4)] : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = (lane >> 4) + 4 * r, col = lane & 15;
+                A[(int64_t)(gi * 16 + row) * np + kb * 16 + col] = acc[r];
+                P[(bi * 16 + row) * CH_LD + col] = acc[r];
+            }
+        }
+        __syncthreads();
+        /* trailing update: A[i][j] -= L_i L_j^T for kb < j <= i */
+        const int ntile = m * (m + 1) / 2;
+        if (g_chol_scalar) {
+            for (int e = tid; e < m * 16 * m * 16; e += BA_T) {
+                const int r = e / (m * 16), c = e % (m * 16);
+                if (c > r) continue;
+                double v = 0;
+                for (int k = 0; k < 16; k++) v += P[r * CH_LD + k] * P[c * CH_LD + k];
+                A[(int64_t)((kb + 1) * 16 + r) * np + (kb + 1) * 16 + c] -= v;
+            }
+        } else
+        for (int t = wave; t < ntile; t += BA_W) {
+            int ii = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+            while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
+            while (ii * (ii + 1) / 2 > t) ii--;
+            const int jj = t - ii * (ii + 1) / 2;
+            const int gi = kb + 1 + ii, gj = kb + 1 + jj;
+            double *C = A + (int64_t)(gi * 16 + (lane >> 4)) * np + gj * 16 + (lane & 15);
+            v4d c4;
+#pragma unroll
+            for (int r = 0; r < 4; r++) c4[r] = C[(int64_t)4 * r * np];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) {
+                const double a = -P[(ii * 16 + (lane & 15)) * CH_LD + 4 * s4 + (lane >> 4)];
+                const double b = P[(jj * 16 + (lane & 15)) * CH_LD + 4 * s4 + (lane >> 4)];
+                c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c4, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) C[(int64_t)4 * r * np] = c4[r];
+        }
+        __syncthreads();
+    }
+    const bool ok = s.bc[0] == 0.0;
+    /* ---- forward substitution L y = g ---- */
+    for (int i = tid; i < np; i += BA_T) z[i] = (i < n) ? D[w.g + i] : 0.0;
+    __syncthreads();
+    for (int kb = 0; kb < nb; kb++) {
+        double v = 0.0;
+        if (tid < 16)
+            for (int k = 0; k < 16; k++) v += Li[kb * 256 + tid * 16 + k] * z[kb * 16 + k];
+        __syncthreads();
+        if (tid < 16) z[kb * 16 + tid] = v;
+        __syncthreads();
+        for (int i = (kb + 1) * 16 + tid; i < np; i += BA_T) {
+            const double *Ar = A + (int64_t)i * np + kb * 16;
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) acc += Ar[k] * z[kb * 16 + k];
+            z[i] -= acc;
+        }
+        __syncthreads();
+    }
+    /* ---- backward substitution L^T x = y ---- */
+    for (int kb = nb - 1; kb >= 0; kb--) {
+        double v = 0.0;
+        if (tid < 16)
+            for (int k = 0; k < 16; k++) v += Li[kb * 256 + k * 16 + tid] * z[kb * 16 + k];
+        __syncthreads();
+        if (tid < 16) z[kb * 16 + tid] = v;
+        __syncthreads();
+        for (int j = tid; j < kb * 16; j += BA_T) {
+            double acc = 0.0;
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc += A[(int64_t)(kb * 16 + r) * np + j] * z[kb * 16 + r];
+            z[j] -= acc;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += BA_T) D[w.x + i] = ok ? z[i] : 0.0;
+    __syncthreads();
+    return ok;
+}
+
 /* one LM iteration (OptimizationAlgorithmLevenberg::solve) for every window of the batch */
 __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of_round, double pcg_tol2, int pcg_maxit,
-                                                       int debug) {
+                                                       int debug, int solver, int dyn_doubles) {
     __shared__ BAShared s;
+    extern __shared__ __attribute__((aligned(16))) double ba_dyn[];
     const BAWin w = bufs.wins[blockIdx.x];
     double *D = bufs.D;
     const int32_t *I = bufs.I;
@@ -522,6 +723,33 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
         }
         __syncthreads();
         BA_STAMP(5)
+        bool ok2 = true;
+        int it = 0;
+        /* linear solver of the reduced camera system: dense blocked Cholesky (MFMA f64) when its LDS panel fits,
+           PCG otherwise / on request */
+        const int np_ = (n + 15) & ~15;
+        const bool use_chol = solver == 1 && n > 0 && (np_ * CH_LD + 2 * 16 * CH_LD + np_) <= dyn_doubles;
+        if (use_chol) {
+            BA_STAMP(5)
+            ok2 = ba_chol_solve(w, D, I, n, ba_dyn, s);
+            solves++;
+            if (debug > 1) { /* residual of the direct solve against the block-sparse S */
+                double r2 = 0, g2 = 0;
+                for (int i = tid; i < n; i += BA_T) {
+                    const int sl_ = i / 6, a_ = i % 6;
+                    double v = 0;
+                    for (int bk = I[w.blk_row + sl_]; bk < I[w.blk_row + sl_ + 1]; bk++)
+                        for (int c = 0; c < 6; c++) v += D[w.S + (int64_t)bk * 36 + a_ * 6 + c] * D[w.x + I[w.blk_col + bk] * 6 + c];
+                    const double gi_ = D[w.g + i];
+                    r2 += (v - gi_) * (v - gi_);
+                    g2 += gi_ * gi_;
+                }
+                r2 = block_sum(r2, s);
+                g2 = block_sum(g2, s);
+                if (tid == 0) printf("[dev] chol residual |Sx-g|/|g| = %.3e (ok %d, n %d)\n", sqrt(r2 / g2), (int)ok2, n);
+            }
+            BA_STAMP(6)
+        } else {
         /* ---- block-Jacobi preconditioner: inverse of the 6x6 diagonal blocks (thread per camera) ---- */
         bool ok_local = true;
         for (int sl = tid; sl < w.Ncf; sl += BA_T) {
@@ -590,8 +818,8 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
         }
         double rz = block_sum(rz_loc, s);
         const double rz0 = rz;
-        bool ok2 = (block_sum(ok_local ? 0.0 : 1.0, s) == 0.0);
-        int it = 0;
+        ok2 = (block_sum(ok_local ? 0.0 : 1.0, s) == 0.0);
+        it = 0;
         if (n > 0 && ok2 && rz0 > 0) {
             for (it = 0; it < pcg_maxit; it++) {
                 /* Ap = S p : block-CSR row product, p read from LDS */
@@ -659,6 +887,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
         for (int q = 0; q < 3; q++) {
             const int i = tid + q * BA_T;
             if (i < n) D[w.x + i] = ok2 ? xi[q] : 0.0;
+        }
         }
         __syncthreads();
         BA_STAMP(7)
@@ -782,6 +1011,7 @@ struct BASolver {
     uint8_t *pB = nullptr;
     size_t pcapD = 0, pcapI = 0, pcapB = 0;
     double pcg_tol2 = 1e-26; /* relative M^-1-norm of the residual, squared */
+    int solver = 1;          /* 1 = dense blocked Cholesky (MFMA f64), 0 = PCG (ORBSLAM_AMD_BA_SOLVER=pcg) */
 };
 
 extern "C" int ba_create(int max_cams, int max_points, int max_obs, int max_batch, int device_id, BASolver **out) {
@@ -805,6 +1035,12 @@ extern "C" int ba_create(int max_cams, int max_points, int max_obs, int max_batc
     }
     const char *tol = getenv("ORBSLAM_AMD_PCG_TOL");
     if (tol) s->pcg_tol2 = atof(tol) * atof(tol);
+    if (getenv("ORBSLAM_AMD_CHOL_SCALAR")) {
+        int one = atoi(getenv("ORBSLAM_AMD_CHOL_SCALAR"));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_chol_scalar), &one, sizeof(int));
+    }
+    const char *sv = getenv("ORBSLAM_AMD_BA_SOLVER");
+    if (sv && !strcmp(sv, "pcg")) s->solver = 0;
     *out = s;
     return ORB_OK;
 }
@@ -854,11 +1090,11 @@ struct HostWin {
 static int64_t BAWin::*const kInputDFields[] = {&BAWin::poses, &BAWin::pts, &BAWin::obs, &BAWin::info, &BAWin::st};
 static int64_t BAWin::*const kIntFields[] = {&BAWin::cam,     &BAWin::pt,      &BAWin::pt_start, &BAWin::cam_start,
                                              &BAWin::cam_edges, &BAWin::slot,  &BAWin::blk_row,  &BAWin::blk_col,
-                                             &BAWin::blk_diag, &BAWin::blk_mirror, &BAWin::blk_upper, &BAWin::con_start, &BAWin::con_e1, &BAWin::con_e2};
+                                             &BAWin::blk_diag, &BAWin::blk_mirror, &BAWin::blk_upper, &BAWin::blk_rowid, &BAWin::con_start, &BAWin::con_e1, &BAWin::con_e2};
 static int64_t BAWin::*const kScratchFields[] = {&BAWin::poses_t, &BAWin::pts_t, &BAWin::err, &BAWin::err_t, &BAWin::W,
                                                  &BAWin::Y,       &BAWin::Hpp,   &BAWin::bp,  &BAWin::Hll,   &BAWin::bl,
                                                  &BAWin::Dinv,    &BAWin::S,     &BAWin::g,   &BAWin::Minv,  &BAWin::x,
-                                                 &BAWin::xl};
+                                                 &BAWin::xl,      &BAWin::A,     &BAWin::Linv};
 
 /* lay one problem out in the host staging vectors; returns error code */
 static int stage_problem(const BAProblem *p, std::vector<double> &hD, size_t &scratchD, std::vector<int32_t> &hI,
@@ -994,6 +1230,11 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hD, size_t &sc
     w.Minv = allocS((size_t)Ncf * 36);
     w.x = allocS((size_t)Ncf * 6);
     w.xl = allocS(2);
+    {
+        const size_t np = ((size_t)Ncf * 6 + 15) & ~(size_t)15;
+        w.A = allocS(np * np);
+        w.Linv = allocS((np / 16) * 256);
+    }
     w.st = allocD(ST_COUNT);
     for (int c = 0; c < Nc; c++) {
         double q[4] = {p->poses[c * 7], p->poses[c * 7 + 1], p->poses[c * 7 + 2], p->poses[c * 7 + 3]};
@@ -1034,6 +1275,9 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hD, size_t &sc
     for (int i = 0; i < Ncf; i++) hI[w.blk_diag + i] = bdiag[i];
     w.blk_mirror = allocI(nnzb);
     for (int i = 0; i < nnzb; i++) hI[w.blk_mirror + i] = bmirror[i];
+    w.blk_rowid = allocI(nnzb);
+    for (int s1 = 0; s1 < Ncf; s1++)
+        for (int bk = brow[s1]; bk < brow[s1 + 1]; bk++) hI[w.blk_rowid + bk] = s1;
     {
         std::vector<int> upper;
         for (int i = 0; i < nnzb; i++)
@@ -1163,6 +1407,19 @@ extern "C" int ba_solve_batch(BASolver *s, const BAProblem *probs, BAResult *res
     for (int i = 0; i < nwin; i++) maxn = std::max(maxn, wins[i].Ncf * 6);
     int pcg_maxit = 6 * maxn + 100; /* CG needs > n steps in floating point when S is ill-conditioned */
     if (getenv("ORBSLAM_AMD_PCG_MAXIT")) pcg_maxit = atoi(getenv("ORBSLAM_AMD_PCG_MAXIT")); /* profiling only */
+    /* dynamic LDS of the Cholesky solver: panel + two 16x16 blocks + rhs, for the largest window of the batch */
+    int dyn_doubles = 0;
+    if (s->solver == 1) {
+        const int npmax = (maxn + 15) & ~15;
+        const size_t need = (size_t)npmax * 17 + 2 * 16 * 17 + npmax;
+        if (need * 8 <= 128 * 1024) dyn_doubles = (int)need; /* larger systems fall back to PCG inside the kernel */
+        static size_t attr_set = 0;
+        if ((size_t)dyn_doubles * 8 > attr_set) {
+            BCHK(hipFuncSetAttribute((const void *)k_ba_iteration, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     dyn_doubles * 8));
+            attr_set = (size_t)dyn_doubles * 8;
+        }
+    }
     bool halted = false;
     for (int round = 0; round < P0.n_rounds && !halted; round++) {
         for (int it = 0; it < P0.rounds[round]; it++) {
@@ -1170,8 +1427,9 @@ extern "C" int ba_solve_batch(BASolver *s, const BAProblem *probs, BAResult *res
                 halted = true;
                 break;
             }
-            hipLaunchKernelGGL(k_ba_iteration, dim3(nwin), dim3(BA_T), 0, s->stream, bufs, it == 0 ? 1 : 0, s->pcg_tol2,
-                               pcg_maxit, getenv("ORBSLAM_AMD_BA_DEBUG") ? 2 : (prof ? 1 : 0));
+            hipLaunchKernelGGL(k_ba_iteration, dim3(nwin), dim3(BA_T), (size_t)dyn_doubles * 8, s->stream, bufs,
+                               it == 0 ? 1 : 0, s->pcg_tol2, pcg_maxit, getenv("ORBSLAM_AMD_BA_DEBUG") ? 2 : (prof ? 1 : 0),
+                               s->solver, dyn_doubles);
             BCHK(hipGetLastError());
             /* the stop flag must be observed between iterations, as the reference's optimizer would */
             bool any_stop_ptr = false;

@@ -1,4 +1,5 @@
-"""GPU parity: device bundle adjustment (PCG on the Schur complement, C-ABI) vs the CPU oracle
+"""GPU parity: device bundle adjustment (in-kernel blocked Cholesky on the Schur complement; PCG kept
+behind ORBSLAM_AMD_BA_SOLVER=pcg; C-ABI) vs the CPU oracle
 (dense Cholesky, g2o semantics).  Tolerance from BASELINE.json north_star: pose / point estimates
 within 1e-5 relative on identical inputs (f64 on both sides)."""
 import numpy as np
@@ -129,3 +130,30 @@ def test_pose_optimization_batch(opt, oracle):
         assert gn[i] == rn and np.array_equal(go[i], ro[:len(go[i])])
         assert np.abs(gp[i] - rp).max() < REL * max(np.abs(rp).max(), 1.0)
     assert gn[3] == 0 and np.array_equal(gp[3], poses[3])
+
+
+def test_ba_cholesky_equals_pcg_many_sizes(oracle):
+    """the two in-kernel linear solvers (blocked Cholesky with f64 MFMA, block-Jacobi PCG) on 48 ragged
+    windows -- every reduced-system size 6..150 pads differently into the 16-wide Cholesky blocks"""
+    import os
+    import orbslam_in_practice_amd as oa
+    from orbslam_in_practice_amd import synth
+    ws = [synth.make_ba_window(4000 + i, 3 + (i % 24), 60 + 17 * i) for i in range(48)]
+    for w in ws:
+        w["fixed"][:2] = 1
+    chol = oa.Optimizer(max_cams=32, max_points=1024, max_obs=16384, max_batch=48)
+    os.environ["ORBSLAM_AMD_BA_SOLVER"] = "pcg"
+    try:
+        pcg = oa.Optimizer(max_cams=32, max_points=1024, max_obs=16384, max_batch=48)
+    finally:
+        del os.environ["ORBSLAM_AMD_BA_SOLVER"]
+    a = chol.solve_batch(ws, (5, 10))
+    b = pcg.solve_batch(ws, (5, 10))
+    for i, (x, y, w) in enumerate(zip(a, b, ws)):
+        assert np.array_equal(x["outlier"], y["outlier"]), i
+        assert _rel(x["points"], y["points"]) < 1e-7, i
+        assert _rel(x["poses"], y["poses"]) < 1e-7, i
+    ref = oracle.ba_solve(ws[17], rounds=(5, 10))
+    assert _rel(a[17]["points"], ref["points"]) < REL
+    chol.close()
+    pcg.close()
