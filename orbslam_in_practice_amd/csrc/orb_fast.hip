@@ -168,41 +168,53 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells(OrbGeom g, const uint8_t 
 /* cornerScore with a run-time LDS row pitch (same packed network as fast_score16) */
 __device__ __forceinline__ int fast_score16_ld(const uint8_t *c, int v, int ld) {
     const uint8_t *rm3 = c - 3 * ld, *rm2 = c - 2 * ld, *rm1 = c - ld, *rp1 = c + ld, *rp2 = c + 2 * ld, *rp3 = c + 3 * ld;
-    int d[16];
-    d[0] = v - rp3[0];
-    d[1] = v - rp3[1];
-    d[2] = v - rp2[2];
-    d[3] = v - rp1[3];
-    d[4] = v - c[3];
-    d[5] = v - rm1[3];
-    d[6] = v - rm2[2];
-    d[7] = v - rm3[1];
-    d[8] = v - rm3[0];
-    d[9] = v - rm3[-1];
-    d[10] = v - rm2[-2];
-    d[11] = v - rm1[-3];
-    d[12] = v - c[-3];
-    d[13] = v - rp1[-3];
-    d[14] = v - rp2[-2];
-    d[15] = v - rp3[-1];
+    /* The network runs on the ring VALUES, not on differences: with p[k] = (r[k], -r[k]) the max over the 16
+     * nine-arcs of the arc minimum is (max-min r, -(min-max r)), and
+     *   bright score = max-min r - v,   dark score = v - min-max r
+     * so the centre enters only at the very end.  r * -65535 = r - (r << 16) packs (r, -r) for 0 <= r <= 255 in
+     * one full-rate v_mul_i32_i24. */
+    int r[16];
+    r[0] = rp3[0];
+    r[1] = rp3[1];
+    r[2] = rp2[2];
+    r[3] = rp1[3];
+    r[4] = c[3];
+    r[5] = rm1[3];
+    r[6] = rm2[2];
+    r[7] = rm3[1];
+    r[8] = rm3[0];
+    r[9] = rm3[-1];
+    r[10] = rm2[-2];
+    r[11] = rm1[-3];
+    r[12] = c[-3];
+    r[13] = rp1[-3];
+    r[14] = rp2[-2];
+    r[15] = rp3[-1];
     v2s p[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        p[k].x = (short)d[k];
-        p[k].y = (short)(-d[k]);
+        const int packed = __mul24(r[k], -65535);
+        p[k] = __builtin_bit_cast(v2s, packed);
     }
     v2s w2[16], w4[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) w2[k] = __builtin_elementwise_min(p[k], p[(k + 1) & 15]);
 #pragma unroll
     for (int k = 0; k < 16; k++) w4[k] = __builtin_elementwise_min(w2[k], w2[(k + 2) & 15]);
-    v2s best = {-1000, -1000};
+    /* level by level (no serial min/max chain: dependent packed ops cost a wait state each on gfx950) */
+    v2s w8[16], w9[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        v2s w9 = __builtin_elementwise_min(__builtin_elementwise_min(w4[k], w4[(k + 4) & 15]), p[(k + 8) & 15]);
-        best = __builtin_elementwise_max(best, w9);
-    }
-    return max((int)best.x, (int)best.y) - 1;
+    for (int k = 0; k < 16; k++) w8[k] = __builtin_elementwise_min(w4[k], w4[(k + 4) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) w9[k] = __builtin_elementwise_min(w8[k], p[(k + 8) & 15]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) w9[k] = __builtin_elementwise_max(w9[k], w9[k + 8]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) w9[k] = __builtin_elementwise_max(w9[k], w9[k + 4]);
+#pragma unroll
+    for (int k = 0; k < 2; k++) w9[k] = __builtin_elementwise_max(w9[k], w9[k + 2]);
+    const v2s best = __builtin_elementwise_max(w9[0], w9[1]);
+    return max((int)best.x - v, (int)best.y + v) - 1;
 }
 
 /* ONE WAVEFRONT per (cell, frame): a 64-thread workgroup, LDS tile sized to the largest cell of the current
