@@ -218,14 +218,18 @@ __device__ __forceinline__ int fast_score16_ld(const uint8_t *c, int v, int ld) 
 }
 
 /* ONE WAVEFRONT per (cell, frame): a 64-thread workgroup, LDS tile sized to the largest cell of the current
- * geometry (about 3 KB at 640x480), ROI staged as aligned dwords.  No cross-wave barrier, no workgroup scan:
- * ordered emission is a running ballot/popcount prefix over 64-pixel row-major chunks. */
-#define FW_MAXCH 64 /* 64-px chunks per cell: 59*59/64 < 55 */
+ * geometry (about 3 KB at 640x480), ROI staged as aligned dwords.  No cross-wave barrier, no workgroup scan.
+ *   pass A  scores of the detection zone in dense 64-pixel row-major chunks; pixels that are corners at
+ *           minThFAST (a few percent) are appended, in order, to an LDS queue by ballot/popcount prefix;
+ *   pass B  3x3 non-maximum suppression of the QUEUED pixels only (64 per step instead of one chunk per 64
+ *           pixels of the cell), flags kept / kept-and->=iniThFAST written back into the queue entry;
+ *   pass C  ordered emission of the queue entries selected by the per-cell threshold fallback. */
 __global__ __launch_bounds__(64) void k_fast_cells_wave(OrbGeom g, const uint8_t *pyr, const CellDesc *cells, uint32_t *slab,
                                                         int32_t *cell_cnt, int ld, int lh) {
     extern __shared__ __attribute__((aligned(16))) uint8_t fw_smem[];
-    uint8_t *s_px = fw_smem;            /* [lh][ld], column 0 <-> x = iniX & ~3 */
-    uint8_t *s_sc = fw_smem + ld * lh;  /* scores, same layout */
+    uint8_t *s_px = fw_smem;                             /* [lh][ld], column 0 <-> x = iniX & ~3 */
+    uint8_t *s_sc = fw_smem + ld * lh;                   /* scores, same layout */
+    uint16_t *s_q = (uint16_t *)(fw_smem + 2 * ld * lh); /* queue: y << 7 | x, bit 14 kept, bit 15 kept at iniTh */
     const int item = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const int frame = item / g.total_cells, cell = item - frame * g.total_cells;
     const CellDesc cd = cells[cell];
@@ -234,9 +238,10 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(OrbGeom g, const uint8_t
     const int ox = cd.iniX & 3;
     const uint8_t *src = level_ptr(pyr, g, frame, cd.level) + (int64_t)cd.iniY * L.pitch + (cd.iniX & ~3);
     const int ndw = (ox + rw + 3) >> 2; /* aligned dwords per ROI row (the pitch is a multiple of 64) */
+    const float inv_ndw = 1.0f / (float)ndw; /* i / ndw without the integer divide: exact for i < 2^12 */
     for (int i = lane; i < rh * ndw; i += 64) {
-        const int r = i / ndw, c4 = i - r * ndw;
-        *(uint32_t *)(s_px + r * ld + c4 * 4) = *(const uint32_t *)(src + (int64_t)r * L.pitch + c4 * 4);
+        const int r = (int)(((float)i + 0.5f) * inv_ndw), c4 = i - __mul24(r, ndw);
+        *(uint32_t *)(s_px + __mul24(r, ld) + c4 * 4) = *(const uint32_t *)(src + __mul24(r, L.pitch) + c4 * 4);
     }
     for (int i = lane; i < (ld * lh) >> 2; i += 64) ((uint32_t *)s_sc)[i] = 0u;
     __syncthreads();
@@ -244,54 +249,60 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(OrbGeom g, const uint8_t
     const int n_in = (iw > 0 && ih > 0) ? iw * ih : 0;
     const float inv_iw = 1.0f / (float)(iw > 0 ? iw : 1);
     const int nch = (n_in + 63) >> 6;
-    /* scores */
+    const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    /* pass A */
+    int nq = 0;
     for (int ch = 0; ch < nch; ch++) {
         const int i = ch * 64 + lane;
+        bool hit = false;
+        int x = 0, y = 0;
         if (i < n_in) {
-            const int y = (int)(((float)i + 0.5f) * inv_iw), x = i - y * iw;
-            const uint8_t *c = s_px + (y + 3) * ld + (x + 3 + ox);
+            const int yy = (int)(((float)i + 0.5f) * inv_iw);
+            x = i - __mul24(yy, iw) + 3 + ox;
+            y = yy + 3;
+            const int pos = __mul24(y, ld) + x; /* 24-bit multiplies: full rate, unlike v_mul_lo_u32 */
+            const uint8_t *c = s_px + pos;
             const int sc = fast_score16_ld(c, (int)c[0], ld);
-            s_sc[(y + 3) * ld + (x + 3 + ox)] = (uint8_t)(sc >= g.min_th ? sc : 0);
+            hit = sc >= g.min_th;
+            if (hit) s_sc[pos] = (uint8_t)sc;
         }
+        const uint64_t m = __ballot(hit);
+        if (hit) s_q[nq + __popcll(m & lt)] = (uint16_t)(y << 7 | x);
+        nq += __popcll(m);
     }
     __syncthreads();
-    /* NMS per chunk; the keep flags (bit0: kept, bit1: kept and >= iniThFAST) go into the pixel tile, which
-       is no longer needed once the scores exist */
+    /* pass B */
     bool any_ini = false;
 #pragma unroll 1
-    for (int ch = 0; ch < nch; ch++) {
-        const int i = ch * 64 + lane;
+    for (int j0 = 0; j0 < nq; j0 += 64) {
+        const int j = j0 + lane;
         bool ki = false;
-        if (i < n_in) {
-            const int y = (int)(((float)i + 0.5f) * inv_iw), x = i - y * iw;
-            const int pos = (y + 3) * ld + (x + 3 + ox);
-            const uint8_t *q = s_sc + pos;
+        if (j < nq) {
+            const int e = s_q[j];
+            const uint8_t *q = s_sc + __mul24((e >> 7) & 127, ld) + (e & 127);
             const int sv = q[0];
-            const bool k = sv > 0 && sv > q[-ld - 1] && sv > q[-ld] && sv > q[-ld + 1] && sv > q[-1] && sv > q[1] &&
-                           sv > q[ld - 1] && sv > q[ld] && sv > q[ld + 1];
+            const bool k = sv > q[-ld - 1] && sv > q[-ld] && sv > q[-ld + 1] && sv > q[-1] && sv > q[1] && sv > q[ld - 1] &&
+                           sv > q[ld] && sv > q[ld + 1];
             ki = k && sv >= g.ini_th;
-            s_px[pos] = (uint8_t)((k ? 1 : 0) | (ki ? 2 : 0));
+            s_q[j] = (uint16_t)(e | (k ? 1 << 14 : 0) | (ki ? 1 << 15 : 0));
         }
         any_ini = any_ini || (__ballot(ki) != 0);
     }
     __syncthreads();
+    /* pass C */
     uint32_t *out = slab + (int64_t)frame * g.slab_frame_count + cd.slab_off;
-    const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const int want = any_ini ? 2 : 1; /* per-cell threshold fallback (:765-773) */
+    const int want = any_ini ? 1 << 15 : 1 << 14; /* per-cell threshold fallback (:765-773) */
     int base = 0;
 #pragma unroll 1
-    for (int ch = 0; ch < nch; ch++) {
-        const int i = ch * 64 + lane;
-        bool sel = false;
-        int x = 0, y = 0, pos = 0;
-        if (i < n_in) {
-            y = (int)(((float)i + 0.5f) * inv_iw);
-            x = i - y * iw;
-            pos = (y + 3) * ld + (x + 3 + ox);
-            sel = (s_px[pos] & want) != 0;
-        }
+    for (int j0 = 0; j0 < nq; j0 += 64) {
+        const int j = j0 + lane;
+        const int e = j < nq ? (int)s_q[j] : 0;
+        const bool sel = (e & want) != 0;
         const uint64_t m = __ballot(sel);
-        if (sel) out[base + __popcll(m & lt)] = KEY_PACK(x + 3 + cd.offX, y + 3 + cd.offY, s_sc[pos]);
+        if (sel) {
+            const int y = (e >> 7) & 127, x = e & 127;
+            out[base + __popcll(m & lt)] = KEY_PACK(x - ox + cd.offX, y + cd.offY, s_sc[__mul24(y, ld) + x]);
+        }
         base += __popcll(m);
     }
     if (lane == 0) cell_cnt[(int64_t)frame * g.total_cells + cell] = base;
@@ -302,7 +313,7 @@ hipError_t launch_fast(const OrbGeom &g, const OrbBuffers &b, int n_frames, hipS
     dim3 grid(g.total_cells, n_frames);
     if (g.cell_max_rw > 0) { /* one wavefront per cell */
         const int ld = (g.cell_max_rw + 3 + 3) & ~3, lh = g.cell_max_rh;
-        hipLaunchKernelGGL(k_fast_cells_wave, grid, dim3(64), (size_t)2 * ld * lh, st, g, (const uint8_t *)b.pyr, b.cells, b.slab,
+        hipLaunchKernelGGL(k_fast_cells_wave, grid, dim3(64), (size_t)2 * ld * lh + 2 * (size_t)(g.cell_max_rw * g.cell_max_rh), st, g, (const uint8_t *)b.pyr, b.cells, b.slab,
                            b.cell_cnt, ld, lh);
         return hipGetLastError();
     }
