@@ -216,6 +216,22 @@ static int build_geom(OrbExtractor *h, int w, int hgt) {
             h->h_tab_i.resize(h->h_tab_i.size() + L.h);
             h->h_tab_c.resize(h->h_tab_c.size() + 2 * L.h);
             resize_tables(S.h, L.h, &h->h_tab_i[L.yofs_off], &h->h_tab_c[2 * L.yofs_off], false);
+            /* LDS window of the largest 128 x 32 output tile (k_resize stages exactly this much) */
+            const int32_t *xo = &h->h_tab_i[L.xofs_off], *yo = &h->h_tab_i[L.yofs_off];
+            int max_dw = 0, max_rows = 0;
+            for (int tx0 = 0; tx0 < L.w; tx0 += 128) {
+                const int x_last = std::min(tx0 + 128, L.w) - 1;
+                const int lo = xo[tx0] & ~3, hi = std::min(xo[x_last] + 1, S.w - 1);
+                max_dw = std::max(max_dw, (hi - lo) / 4 + 1);
+            }
+            for (int ty0 = 0; ty0 < L.h; ty0 += 32) {
+                const int y_last = std::min(ty0 + 32, L.h) - 1;
+                const int lo = std::min(std::max(yo[ty0], 0), S.h - 1), hi = std::min(std::max(yo[y_last] + 1, 0), S.h - 1);
+                max_rows = std::max(max_rows, hi - lo + 1);
+            }
+            L.rs_lw = max_dw * 4;
+            L.rs_lh = max_rows;
+            if ((int64_t)L.rs_lw * L.rs_lh > 40 * 1024) L.rs_lw = L.rs_lh = 0; /* huge scale step: gather path */
         }
         /* FAST cell grid, src/ORBextractor.cpp:729-762 */
         const int minB = ORB_MIN_BORDER;

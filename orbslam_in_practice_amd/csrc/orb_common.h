@@ -38,6 +38,7 @@ struct LevelGeom {
     float patch_size;         /* (int)(31*scale) as float (:793)                                   */
     /* resize tables (level l from level l-1): offsets into the coefficient table buffer */
     int xofs_off, yofs_off;   /* int index tables                                                  */
+    int rs_lw, rs_lh;         /* resize: LDS source window (bytes per row, rows) of the largest 128x32 tile; 0 = gather path */
 };
 
 struct OrbGeom {

@@ -46,17 +46,16 @@ __global__ __launch_bounds__(256) void k_copy_level0(OrbGeom g, uint8_t *pyr, co
 }
 
 /* ---- level l from level l-1, cv::resize INTER_LINEAR fixed point -------------------------------- */
-/* One workgroup = a 128 x 8 output tile.  The source rows/columns it touches ((8*s+2) x (128*s+2) pixels,
- * s = scale step <= 2) are staged in LDS as aligned dwords (row-coalesced), then every thread produces 4
- * adjacent pixels from LDS bytes and the packed per-column {sx, a0, a1} / per-row {sy, b0, b1} tables
- * (one 8-byte table load per pixel instead of three), and stores one u32. */
+/* One workgroup = a 128 x 32 output tile.  The source window it touches is staged in LDS as aligned dwords
+ * (row-coalesced; window size per level computed on the host from the same tables, LevelGeom::rs_lw/rs_lh).
+ * A thread owns 4 adjacent output columns -- their {sx, a0, a1} table entries are loaded once and stay in
+ * registers -- and walks 4 output rows (y, y+8, y+16, y+24), one packed u32 store per row.  All index
+ * arithmetic is 24-bit multiplies / float reciprocals: no v_mul_lo_u32, no integer division in the loops. */
 #define RS_TW 128
-#define RS_TH 8
-#define RS_LW 288 /* staged bytes per source row: 128 * 2 + slack, multiple of 4 */
-#define RS_LH 20  /* staged source rows: 8 * 2 + slack */
+#define RS_TH 32
 __global__ __launch_bounds__(256) void k_resize(OrbGeom g, uint8_t *pyr, const int32_t *tab_i, const int16_t *tab_c,
                                                  int level) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_src[RS_LH][RS_LW];
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_src[];
     const LevelGeom &L = g.lv[level];
     const LevelGeom &S = g.lv[level - 1];
     const int nbx = gridDim.x, nby = gridDim.y;
@@ -66,66 +65,104 @@ __global__ __launch_bounds__(256) void k_resize(OrbGeom g, uint8_t *pyr, const i
     const int tx0 = bx * RS_TW, ty0 = by * RS_TH;
     const int tid = threadIdx.x;
     const uint8_t *src = level_ptr(pyr, g, frame, level - 1);
+    uint8_t *dst = level_ptr(pyr, g, frame, level);
     const int32_t *xofs = tab_i + L.xofs_off;
     const int32_t *yofs = tab_i + L.yofs_off;
-    const int16_t *ialpha = tab_c + 2 * L.xofs_off;
-    const int16_t *ibeta = tab_c + 2 * L.yofs_off;
-    /* source window of this tile */
-    const int x_last = min(tx0 + RS_TW, L.w) - 1, y_last = min(ty0 + RS_TH, L.h) - 1;
-    const int sx_lo = xofs[tx0] & ~3;                                   /* xofs is non-decreasing and >= 0 */
-    const int sx_hi = min(xofs[x_last] + 1, S.w - 1);
-    const int sy_lo = min(max(yofs[ty0], 0), S.h - 1);
-    const int sy_hi = min(max(yofs[y_last] + 1, 0), S.h - 1);
-    const int ndw = (sx_hi - sx_lo) / 4 + 1, nrow = sy_hi - sy_lo + 1;
-    if (ndw * 4 <= RS_LW && nrow <= RS_LH) {
-        for (int i = tid; i < nrow * ndw; i += 256) {
-            const int r = i / ndw, c4 = i - r * ndw;
-            /* the pitch is a multiple of 64 and planes are 256-B aligned: the dword stays inside the plane */
-            *(uint32_t *)&s_src[r][c4 * 4] = *(const uint32_t *)(src + (int64_t)(sy_lo + r) * S.pitch + sx_lo + c4 * 4);
-        }
-        __syncthreads();
-        const int y = ty0 + (tid >> 5), x0 = tx0 + (tid & 31) * 4;
-        if (y >= L.h || x0 >= L.w) return;
-        const int sy = yofs[y];
-        const int r0 = min(max(sy, 0), S.h - 1) - sy_lo, r1 = min(max(sy + 1, 0), S.h - 1) - sy_lo;
-        const int b0 = ibeta[2 * y], b1 = ibeta[2 * y + 1];
-        uint32_t packed = 0;
+    const uint32_t *ialpha = (const uint32_t *)(tab_c + 2 * L.xofs_off); /* (a0, a1) pairs, 4-byte aligned */
+    const uint32_t *ibeta = (const uint32_t *)(tab_c + 2 * L.yofs_off);
+    const int lw = L.rs_lw;
+    if (lw > 0) {
+        /* Every table read of this thread is issued up front so that they share ONE memory round trip: the four
+           window bounds of the tile (lanes 0..3 of each wave fetch one each, broadcast by v_readlane), the
+           {sx, a0a1} entries of its 4 columns and the {sy, b0b1} entries of its 4 rows. */
+        const int x_last = min(tx0 + RS_TW, L.w) - 1, y_last = min(ty0 + RS_TH, L.h) - 1;
+        const int sel = tid & 3;
+        const int32_t *bp = sel == 0 ? xofs + tx0 : sel == 1 ? xofs + x_last : sel == 2 ? yofs + ty0 : yofs + y_last;
+        const int bound = *bp;
+        const int x0 = tx0 + (tid & 31) * 4;
+        int sxv[4], syv[RS_TH / 8];
+        uint32_t av[4], bv[RS_TH / 8];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int x = x0 + i;
-            if (x < L.w) {
-                const int sx = xofs[x];
-                const int c0 = sx - sx_lo, c1 = min(sx + 1, S.w - 1) - sx_lo;
-                const int a0 = ialpha[2 * x], a1 = ialpha[2 * x + 1];
-                const int h0 = s_src[r0][c0] * a0 + s_src[r0][c1] * a1;
-                const int h1 = s_src[r1][c0] * a0 + s_src[r1][c1] * a1;
-                const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-                packed |= (uint32_t)(v & 0xFF) << (8 * i);
-            }
+            const int x = min(x0 + i, L.w - 1);
+            sxv[i] = xofs[x];
+            av[i] = ialpha[x];
         }
-        *(uint32_t *)(level_ptr(pyr, g, frame, level) + (int64_t)y * L.pitch + x0) = packed;
+#pragma unroll
+        for (int rr = 0; rr < RS_TH / 8; rr++) {
+            const int y = min(ty0 + (tid >> 5) + 8 * rr, L.h - 1);
+            syv[rr] = yofs[y];
+            bv[rr] = ibeta[y];
+        }
+        /* source window of this tile */
+        const int sx_lo = __builtin_amdgcn_readlane(bound, 0) & ~3; /* xofs is non-decreasing and >= 0 */
+        const int sx_hi = min(__builtin_amdgcn_readlane(bound, 1) + 1, S.w - 1);
+        const int sy_lo = min(max(__builtin_amdgcn_readlane(bound, 2), 0), S.h - 1);
+        const int sy_hi = min(max(__builtin_amdgcn_readlane(bound, 3) + 1, 0), S.h - 1);
+        const int ndw = (sx_hi - sx_lo) / 4 + 1, nrow = sy_hi - sy_lo + 1;
+        const float inv_ndw = 1.0f / (float)ndw;
+        const uint8_t *win = src + (int64_t)sy_lo * S.pitch + sx_lo;
+        for (int i = tid; i < nrow * ndw; i += 256) {
+            const int r = (int)(((float)i + 0.5f) * inv_ndw), c4 = i - __mul24(r, ndw);
+            /* the pitch is a multiple of 64 and planes are 256-B aligned: the dword stays inside the plane */
+            *(uint32_t *)(s_src + __mul24(r, lw) + c4 * 4) = *(const uint32_t *)(win + __mul24(r, S.pitch) + c4 * 4);
+        }
+        __syncthreads();
+        if (x0 >= L.w) return;
+        /* bilinear coefficients are non-negative (0..2048): unsigned arithmetic with visible bit widths lets the
+           compiler pick the full-rate 24-bit multiplies */
+        int c0[4], c1[4];
+        uint32_t a0[4], a1[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            c0[i] = sxv[i] - sx_lo;
+            c1[i] = min(sxv[i] + 1, S.w - 1) - sx_lo;
+            a0[i] = av[i] & 0xFFFFu;
+            a1[i] = av[i] >> 16;
+        }
+#pragma unroll
+        for (int rr = 0; rr < RS_TH / 8; rr++) {
+            const int y = ty0 + (tid >> 5) + 8 * rr;
+            if (y >= L.h) break;
+            const int sy = syv[rr];
+            const uint32_t b0 = bv[rr] & 0xFFFFu, b1 = bv[rr] >> 16;
+            const uint8_t *p0 = s_src + __mul24(min(max(sy, 0), S.h - 1) - sy_lo, lw);
+            const uint8_t *p1 = s_src + __mul24(min(max(sy + 1, 0), S.h - 1) - sy_lo, lw);
+            uint32_t packed = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t h0 = (uint32_t)p0[c0[i]] * a0[i] + (uint32_t)p0[c1[i]] * a1[i];
+                const uint32_t h1 = (uint32_t)p1[c0[i]] * a0[i] + (uint32_t)p1[c1[i]] * a1[i];
+                const uint32_t v = (((b0 * ((h0 >> 4) & 0xFFFFu)) >> 16) + ((b1 * ((h1 >> 4) & 0xFFFFu)) >> 16) + 2) >> 2;
+                packed |= (v & 0xFF) << (8 * i);
+            }
+            /* columns past the level width are padding inside the 64-byte-aligned pitch */
+            *(uint32_t *)(dst + __mul24(y, L.pitch) + x0) = packed;
+        }
         return;
     }
-    /* generic path (scale steps > 2 between levels: the window does not fit the LDS tile): direct gathers */
-    {
-        const int y = ty0 + (tid >> 5), x0 = tx0 + (tid & 31) * 4;
+    /* generic path (a scale step so large that the window does not fit the LDS budget): direct gathers */
+    for (int rr = 0; rr < RS_TH / 8; rr++) {
+        const int y = ty0 + (tid >> 5) + 8 * rr, x0 = tx0 + (tid & 31) * 4;
         if (y >= L.h || x0 >= L.w) return;
         const int sy = yofs[y];
         const uint8_t *r0 = src + (int64_t)min(max(sy, 0), S.h - 1) * S.pitch;
         const uint8_t *r1 = src + (int64_t)min(max(sy + 1, 0), S.h - 1) * S.pitch;
-        const int b0 = ibeta[2 * y], b1 = ibeta[2 * y + 1];
+        const uint32_t b = ibeta[y];
+        const int b0 = (int)(int16_t)(b & 0xFFFF), b1 = (int)(int16_t)(b >> 16);
         uint32_t packed = 0;
         for (int i = 0; i < 4; i++) {
             const int x = x0 + i;
             if (x < L.w) {
                 const int sx = xofs[x], sx1 = min(sx + 1, S.w - 1);
-                const int a0 = ialpha[2 * x], a1 = ialpha[2 * x + 1];
+                const uint32_t a = ialpha[x];
+                const int a0 = (int)(int16_t)(a & 0xFFFF), a1 = (int)(int16_t)(a >> 16);
                 const int h0 = r0[sx] * a0 + r0[sx1] * a1, h1 = r1[sx] * a0 + r1[sx1] * a1;
                 const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
                 packed |= (uint32_t)(v & 0xFF) << (8 * i);
             }
         }
-        *(uint32_t *)(level_ptr(pyr, g, frame, level) + (int64_t)y * L.pitch + x0) = packed;
+        *(uint32_t *)(dst + (int64_t)y * L.pitch + x0) = packed;
     }
 }
 
@@ -233,7 +270,7 @@ hipError_t launch_pyramid(const OrbGeom &g, const OrbBuffers &b, const uint8_t *
     hipLaunchKernelGGL(k_copy_level0, grid0, dim3(256), 0, st, g, b.pyr, d_imgs, stride, frame_stride, vec16);
     for (int l = 1; l < g.nlevels; l++) {
         dim3 grid((g.lv[l].w + RS_TW - 1) / RS_TW, (g.lv[l].h + RS_TH - 1) / RS_TH, n_frames);
-        hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, g, b.pyr, b.tab_i, b.tab_c, l);
+        hipLaunchKernelGGL(k_resize, grid, dim3(256), (size_t)g.lv[l].rs_lw * g.lv[l].rs_lh, st, g, b.pyr, b.tab_i, b.tab_c, l);
     }
     return hipGetLastError();
 }
