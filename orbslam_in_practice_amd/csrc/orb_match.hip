@@ -20,6 +20,7 @@
  * depends on that order, so each candidate carries the key (dist << 32 | cell << 16 | index).
  */
 #include "orb_common.h"
+#include <type_traits>
 
 #include <cstring>
 #include <string>
@@ -124,14 +125,24 @@ __device__ __forceinline__ uint32_t f2_order_key(const OrbKeyPoint &kp, int j, b
 }
 
 /* PHASE 1 (fully parallel): for every query i1 the MK_TOP smallest (dist, order) keys over ALL its window
- * candidates, ignoring the greedy vMatchedDistance filter.  One query per lane, F2 streamed through LDS in
- * 512-keypoint tiles (descriptors + positions + order keys), every LDS read a wave-wide broadcast. */
+ * candidates, ignoring the greedy vMatchedDistance filter.  One query per lane; F2 is streamed through LDS in
+ * 512-keypoint tiles from which only the keypoints that can be a candidate of ANY query are kept (windowed
+ * variant: octave 0 and inside the grid -- about a fifth of a frame), compacted with an LDS counter: the
+ * result is a set of unique keys, so the staging order is irrelevant.  Every LDS read in the scan is a
+ * wave-wide broadcast.  Workgroups without a single active query (all octaves > 0) leave before staging.
+ * KEY32: the (dist, cell, index) key packed into 32 bits (9 + 12 + 11, or dist << 16 | j for the brute-force
+ * variant) so that the sorted insert works on single registers; it is widened to the 64-bit format of phase 2
+ * on the way out.  Used whenever the slab capacity allows (cap <= 2048, resp. <= 65536). */
 #define MK_TILE 512
 #define MK_TOP 8 /* keys kept per query; phase 2 rescans only if fewer than two of them are still allowed */
+template <bool KEY32>
 __global__ __launch_bounds__(256) void k_match_knn(MatchArgs A) {
     __shared__ uint4 s_d[MK_TILE * 2];
     __shared__ float s_x[MK_TILE], s_y[MK_TILE];
     __shared__ uint32_t s_o[MK_TILE];
+    __shared__ int s_nc;
+    typedef typename std::conditional<KEY32, uint32_t, uint64_t>::type key_t;
+    const key_t KNONE = (key_t)~(key_t)0;
     const int pair = blockIdx.y;
     const int fa = A.pair_a ? A.pair_a[pair] : 2 * pair, fb = A.pair_b ? A.pair_b[pair] : 2 * pair + 1;
     const int n1 = A.counts[fa], n2 = A.counts[fb];
@@ -159,28 +170,42 @@ __global__ __launch_bounds__(256) void k_match_knn(MatchArgs A) {
         a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w;
         a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
     }
-    uint64_t bk[MK_TOP]; /* the MK_TOP smallest keys, ascending */
+    key_t bk[MK_TOP]; /* the MK_TOP smallest keys, ascending */
 #pragma unroll
-    for (int k = 0; k < MK_TOP; k++) bk[k] = ~0ull;
-    for (int t0 = 0; t0 < n2; t0 += MK_TILE) {
+    for (int k = 0; k < MK_TOP; k++) bk[k] = KNONE;
+    const bool any_active = __syncthreads_or(active) != 0;
+    for (int t0 = 0; any_active && t0 < n2; t0 += MK_TILE) {
         const int nt = min(MK_TILE, n2 - t0);
         __syncthreads();
-        const uint4 *src = (const uint4 *)(D2 + (size_t)t0 * 32);
-        for (int i = threadIdx.x; i < nt * 2; i += 256) s_d[i] = src[i];
+        if (threadIdx.x == 0) s_nc = 0;
+        __syncthreads();
         for (int i = threadIdx.x; i < nt; i += 256) {
             const OrbKeyPoint kp = k2[t0 + i];
-            s_x[i] = kp.x;
-            s_y[i] = kp.y;
-            s_o[i] = f2_order_key(kp, t0 + i, brute, A.min_x, A.min_y, invW, invH);
+            const uint32_t ord = f2_order_key(kp, t0 + i, brute, A.min_x, A.min_y, invW, invH);
+            if (ord != 0xFFFFFFFFu) {
+                const int slot = atomicAdd(&s_nc, 1);
+                const uint4 *src = (const uint4 *)(D2 + (size_t)(t0 + i) * 32);
+                s_d[2 * slot] = src[0];
+                s_d[2 * slot + 1] = src[1];
+                s_x[slot] = kp.x;
+                s_y[slot] = kp.y;
+                /* 32-bit form: cell << 11 | index (windowed), index (brute force) */
+                s_o[slot] = (KEY32 && !brute) ? ((ord >> 16) << 11 | (ord & 0x7FFu)) : ord;
+            }
         }
         __syncthreads();
+        const int nc = s_nc;
         if (active) {
-            for (int j = 0; j < nt; j++) {
+            for (int j = 0; j < nc; j++) {
                 const uint32_t ord = s_o[j];
-                bool cand = ord != 0xFFFFFFFFu;
-                if (!brute) cand = cand && fabsf(s_x[j] - px) < r && fabsf(s_y[j] - py) < r;
+                bool cand = true;
+                if (!brute) cand = fabsf(s_x[j] - px) < r && fabsf(s_y[j] - py) < r;
                 const int d = hamming256(a, s_d[2 * j], s_d[2 * j + 1]);
-                const uint64_t key = cand ? (((uint64_t)(uint32_t)d << 32) | ord) : ~0ull;
+                key_t key;
+                if (KEY32)
+                    key = cand ? (((uint32_t)d << (brute ? 16 : 23)) | ord) : KNONE;
+                else
+                    key = cand ? (key_t)(((uint64_t)(uint32_t)d << 32) | ord) : KNONE;
                 if (key < bk[MK_TOP - 1]) { /* rare once the list has warmed up: sorted insert (keys are unique) */
 #pragma unroll
                     for (int k = MK_TOP - 1; k > 0; k--) bk[k] = key < bk[k - 1] ? bk[k - 1] : (key < bk[k] ? key : bk[k]);
@@ -190,9 +215,23 @@ __global__ __launch_bounds__(256) void k_match_knn(MatchArgs A) {
         }
     }
     if (i1 < n1) {
+        uint64_t out[MK_TOP];
+#pragma unroll
+        for (int k = 0; k < MK_TOP; k++) {
+            if (!KEY32) {
+                out[k] = (uint64_t)bk[k];
+            } else if (bk[k] == KNONE) {
+                out[k] = ~0ull;
+            } else if (brute) {
+                out[k] = ((uint64_t)((uint32_t)bk[k] >> 16) << 32) | ((uint32_t)bk[k] & 0xFFFFu);
+            } else {
+                const uint32_t k32 = (uint32_t)bk[k];
+                out[k] = ((uint64_t)(k32 >> 23) << 32) | (uint64_t)((((k32 >> 11) & 0xFFFu) << 16) | (k32 & 0x7FFu));
+            }
+        }
 #pragma unroll
         for (int k = 0; k < MK_TOP / 2; k++)
-            A.knn[((size_t)pair * A.cap + i1) * (MK_TOP / 2) + k] = make_ulonglong2(bk[2 * k], bk[2 * k + 1]);
+            A.knn[((size_t)pair * A.cap + i1) * (MK_TOP / 2) + k] = make_ulonglong2(out[2 * k], out[2 * k + 1]);
     }
 }
 
@@ -606,7 +645,10 @@ static int launch_match(const MatchArgs &A_in, int n_pairs, hipStream_t st) {
         MCHK(hipFuncSetAttribute((const void *)k_match_init, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = lds;
     }
-    hipLaunchKernelGGL(k_match_knn, dim3((A.cap + 255) / 256, n_pairs), dim3(256), 0, st, A);
+    if (A.cap <= (A.window < 0 ? 65536 : 2048))
+        hipLaunchKernelGGL(k_match_knn<true>, dim3((A.cap + 255) / 256, n_pairs), dim3(256), 0, st, A);
+    else
+        hipLaunchKernelGGL(k_match_knn<false>, dim3((A.cap + 255) / 256, n_pairs), dim3(256), 0, st, A);
     MCHK(hipGetLastError());
     hipLaunchKernelGGL(k_match_init, dim3(n_pairs), dim3(64), lds, st, A);
     MCHK(hipGetLastError());
