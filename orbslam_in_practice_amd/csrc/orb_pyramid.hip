@@ -177,11 +177,21 @@ __device__ __forceinline__ int reflect101(int p, int n) {
 
 /* 64 x 32 output tile per workgroup.  Staging: rows [ty0-3, ty0+35) x bytes [tx0-4, tx0+68) as aligned
  * dwords (18 per row, coalesced); tiles that touch the left/right image edge take the byte path with
- * REFLECT_101 indexing.  Horizontal pass: 4 adjacent pixels per thread from 3 LDS dwords -> 4 x u16.
- * Vertical pass: a 4-pixel x 4-row strip per thread (10 LDS reads of 8 B), one packed u32 store per row. */
+ * REFLECT_101 indexing.
+ * Horizontal pass: 4 adjacent pixels per thread from 3 LDS dwords; the 7 taps of one pixel are two
+ * v_dot4_u32_u8 over byte windows cut out with v_alignbyte_b32 (taps {18,34,49,55} and {49,34,18,0}).
+ * The 16-bit row sums (<= 255 * 257) are stored as VERTICAL pairs -- dword (m, x) = rows (2m, 2m+1) of column
+ * x -- so that the vertical pass is four v_dot2_u32_u16 per pixel: output rows 2t and 2t+1 both read the pairs
+ * t..t+3, with taps {18,34}{49,55}{49,34}{18,0} resp. {0,18}{34,49}{55,49}{34,18}.  One thread = 4 columns x
+ * 2 rows; the rounding constant rides in the accumulator.  Exact integer arithmetic in any order, so the
+ * result equals the separable row-then-column filter of the reference bit for bit. */
+typedef unsigned short blur_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t blur_dot2(uint32_t pair, uint32_t taps, uint32_t acc) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(blur_us2, pair), __builtin_bit_cast(blur_us2, taps), acc, false);
+}
 __global__ __launch_bounds__(256) void k_blur(OrbGeom g, const uint8_t *pyr, uint8_t *blur, TileMap tm) {
     __shared__ __attribute__((aligned(16))) uint8_t s_in[BL_TH + 6][BL_TW + 8];   /* column c <-> x = tx0 - 4 + c */
-    __shared__ __attribute__((aligned(16))) uint16_t s_h[BL_TH + 6][BL_TW];
+    __shared__ __attribute__((aligned(16))) uint32_t s_hp[(BL_TH + 6) / 2][BL_TW]; /* row pairs of the horizontal pass */
     const int item = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const int frame = item / (int)gridDim.x, bx = item - frame * (int)gridDim.x;
     int level = 0;
@@ -197,62 +207,65 @@ __global__ __launch_bounds__(256) void k_blur(OrbGeom g, const uint8_t *pyr, uin
         for (int i = tid; i < (BL_TH + 6) * 18; i += 256) {
             const int r = i / 18, c4 = i - r * 18;
             const int y = reflect101(ty0 + r - 3, L.h);
-            *(uint32_t *)&s_in[r][c4 * 4] = *(const uint32_t *)(src + (int64_t)y * L.pitch + (tx0 - 4) + c4 * 4);
+            *(uint32_t *)&s_in[r][c4 * 4] = *(const uint32_t *)(src + __mul24(y, L.pitch) + (tx0 - 4) + c4 * 4);
         }
     } else {
         for (int i = tid; i < (BL_TH + 6) * (BL_TW + 8); i += 256) {
             const int r = i / (BL_TW + 8), c = i - r * (BL_TW + 8);
             const int y = reflect101(ty0 + r - 3, L.h), x = reflect101(tx0 - 4 + c, L.w);
-            s_in[r][c] = src[(int64_t)y * L.pitch + x];
+            s_in[r][c] = src[__mul24(y, L.pitch) + x];
         }
     }
     __syncthreads();
     /* horizontal: outputs x = tx0 + 4q .. +3 need bytes (4q+1 .. 4q+10) of the staged row */
+    const uint32_t T1 = 18u | 34u << 8 | 49u << 16 | 55u << 24, T2 = 49u | 34u << 8 | 18u << 16;
     for (int i = tid; i < (BL_TH + 6) * 16; i += 256) {
         const int r = i >> 4, q = i & 15;
         const uint32_t *p = (const uint32_t *)&s_in[r][q * 4];
         const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
-        int b[12];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            b[k] = (w0 >> (8 * k)) & 0xFF;
-            b[4 + k] = (w1 >> (8 * k)) & 0xFF;
-            b[8 + k] = (w2 >> (8 * k)) & 0xFF;
-        }
         uint32_t o[4];
+        o[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), T1,
+                                      __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), T2, 0u, false), false);
+        o[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), T1,
+                                      __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), T2, 0u, false), false);
+        o[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), T1,
+                                      __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), T2, 0u, false), false);
+        o[3] = __builtin_amdgcn_udot4(w1, T1, __builtin_amdgcn_udot4(w2, T2, 0u, false), false);
+        uint16_t *hp = (uint16_t *)&s_hp[r >> 1][q * 4] + (r & 1);
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-            o[k] = 18 * (b[k + 1] + b[k + 7]) + 34 * (b[k + 2] + b[k + 6]) + 49 * (b[k + 3] + b[k + 5]) + 55 * b[k + 4];
-        *(uint2 *)&s_h[r][q * 4] = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16)); /* each <= 65535 */
+        for (int k = 0; k < 4; k++) hp[2 * k] = (uint16_t)o[k]; /* each <= 65535 */
     }
     __syncthreads();
-    /* vertical: thread -> (column group q, row group rg of 4 rows) ; 16 x 8 = 128 strips, two passes of 256 thr */
+    /* vertical: thread -> (column group q of 4, output rows 2*rg and 2*rg+1) */
     {
-        const int q = tid & 15, rg = tid >> 4; /* rg 0..15: rows rg*2 .. rg*2+1 */
-        const int x = tx0 + q * 4;
-        if (x < L.w) {
-            uint2 rows[8];
+        const int q = tid & 15, rg = tid >> 4;
+        const int x = tx0 + q * 4, y0 = ty0 + rg * 2;
+        if (x < L.w && y0 < L.h) {
+            uint4 pr[4];
 #pragma unroll
-            for (int k = 0; k < 8; k++) rows[k] = *(const uint2 *)&s_h[rg * 2 + k][q * 4];
+            for (int k = 0; k < 4; k++) pr[k] = *(const uint4 *)&s_hp[rg + k][q * 4];
+            const uint32_t E0 = 18u | 34u << 16, E1 = 49u | 55u << 16, E2 = 49u | 34u << 16, E3 = 18u;
+            const uint32_t O0 = 18u << 16, O1 = 34u | 49u << 16, O2 = 55u | 49u << 16, O3 = 34u | 18u << 16;
+            uint32_t pe = 0, po = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t c0 = k == 0 ? pr[0].x : k == 1 ? pr[0].y : k == 2 ? pr[0].z : pr[0].w;
+                const uint32_t c1 = k == 0 ? pr[1].x : k == 1 ? pr[1].y : k == 2 ? pr[1].z : pr[1].w;
+                const uint32_t c2 = k == 0 ? pr[2].x : k == 1 ? pr[2].y : k == 2 ? pr[2].z : pr[2].w;
+                const uint32_t c3 = k == 0 ? pr[3].x : k == 1 ? pr[3].y : k == 2 ? pr[3].z : pr[3].w;
+                uint32_t e = blur_dot2(c3, E3, blur_dot2(c2, E2, blur_dot2(c1, E1, blur_dot2(c0, E0, 1u << 15))));
+                uint32_t o = blur_dot2(c3, O3, blur_dot2(c2, O2, blur_dot2(c1, O1, blur_dot2(c0, O0, 1u << 15))));
+                e = min(e >> 16, 255u);
+                o = min(o >> 16, 255u);
+                pe |= e << (8 * k);
+                po |= o << (8 * k);
+            }
 #pragma unroll
             for (int rr = 0; rr < 2; rr++) {
-                const int y = ty0 + rg * 2 + rr;
+                const int y = y0 + rr;
                 if (y < L.h) {
-                    uint32_t packed = 0;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        int v[7];
-#pragma unroll
-                        for (int m = 0; m < 7; m++) {
-                            const uint32_t wd = (k < 2) ? rows[rr + m].x : rows[rr + m].y;
-                            v[m] = (k & 1) ? (int)(wd >> 16) : (int)(wd & 0xFFFF);
-                        }
-                        int sum = 18 * (v[0] + v[6]) + 34 * (v[1] + v[5]) + 49 * (v[2] + v[4]) + 55 * v[3];
-                        int o = (sum + (1 << 15)) >> 16;
-                        o = o > 255 ? 255 : o;
-                        packed |= (uint32_t)o << (8 * k);
-                    }
-                    uint8_t *d = dst + (int64_t)y * L.pitch + x;
+                    const uint32_t packed = rr ? po : pe;
+                    uint8_t *d = dst + __mul24(y, L.pitch) + x;
                     if (x + 4 <= L.w)
                         *(uint32_t *)d = packed;
                     else
