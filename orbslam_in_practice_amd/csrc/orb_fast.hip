@@ -165,14 +165,17 @@ __global__ __launch_bounds__(256, 8) void k_fast_cells(OrbGeom g, const uint8_t 
 }
 
 
-/* cornerScore with a run-time LDS row pitch (same packed network as fast_score16) */
+/* ---- one wavefront per cell -------------------------------------------------------------------------- */
+/* cornerScore with a run-time LDS row pitch.  The network runs on the ring VALUES, not on differences: with
+ * p[k] = (r[k], -r[k]) (low / high 16 bits; r * -65535 = r - (r << 16), one full-rate v_mul_i32_i24) the max
+ * over the 16 nine-arcs of the arc minimum is (max-min r, -(min-max r)), and
+ *   bright score = max-min r - v,   dark score = v - min-max r
+ * so ONE log-step sliding-minimum network of v_pk_min_i16 / v_pk_max_i16 serves both polarities; it is ordered
+ * level by level (dependent packed ops cost a wait state each on gfx950). */
 __device__ __forceinline__ int fast_score16_ld(const uint8_t *c, int v, int ld) {
     const uint8_t *rm3 = c - 3 * ld, *rm2 = c - 2 * ld, *rm1 = c - ld, *rp1 = c + ld, *rp2 = c + 2 * ld, *rp3 = c + 3 * ld;
-    /* The network runs on the ring VALUES, not on differences: with p[k] = (r[k], -r[k]) the max over the 16
-     * nine-arcs of the arc minimum is (max-min r, -(min-max r)), and
-     *   bright score = max-min r - v,   dark score = v - min-max r
-     * so the centre enters only at the very end.  r * -65535 = r - (r << 16) packs (r, -r) for 0 <= r <= 255 in
-     * one full-rate v_mul_i32_i24. */
+    /* ring in OpenCV's order: (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)
+       (-3,0)(-3,1)(-2,2)(-1,3) */
     int r[16];
     r[0] = rp3[0];
     r[1] = rp3[1];
@@ -196,13 +199,11 @@ __device__ __forceinline__ int fast_score16_ld(const uint8_t *c, int v, int ld) 
         const int packed = __mul24(r[k], -65535);
         p[k] = __builtin_bit_cast(v2s, packed);
     }
-    v2s w2[16], w4[16];
+    v2s w2[16], w4[16], w8[16], w9[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) w2[k] = __builtin_elementwise_min(p[k], p[(k + 1) & 15]);
 #pragma unroll
     for (int k = 0; k < 16; k++) w4[k] = __builtin_elementwise_min(w2[k], w2[(k + 2) & 15]);
-    /* level by level (no serial min/max chain: dependent packed ops cost a wait state each on gfx950) */
-    v2s w8[16], w9[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) w8[k] = __builtin_elementwise_min(w4[k], w4[(k + 4) & 15]);
 #pragma unroll
@@ -217,12 +218,56 @@ __device__ __forceinline__ int fast_score16_ld(const uint8_t *c, int v, int ld) 
     return max((int)best.x - v, (int)best.y + v) - 1;
 }
 
-/* ONE WAVEFRONT per (cell, frame): a 64-thread workgroup, LDS tile sized to the largest cell of the current
- * geometry (about 3 KB at 640x480), ROI staged as aligned dwords.  No cross-wave barrier, no workgroup scan.
- *   pass A  scores of the detection zone in dense 64-pixel row-major chunks; pixels that are corners at
- *           minThFAST (a few percent) are appended, in order, to an LDS queue by ballot/popcount prefix;
- *   pass B  3x3 non-maximum suppression of the QUEUED pixels only (64 per step instead of one chunk per 64
- *           pixels of the cell), flags kept / kept-and->=iniThFAST written back into the queue entry;
+/* Is the pixel a FAST-9/16 corner at threshold t (<=> cornerScore >= t)?
+ * With V = (t - v) << 16 | (t + v), the word X[k] = V + 65535 * r[k] (one v_mad_u32_u24) holds t + v - r[k] in
+ * its low half and t - v + r[k] in its high half: sign bit 15 set <=> ring pixel brighter than v + t, sign bit
+ * 31 set <=> darker than v - t.  (A negative low half borrows 1 from the high half, but then r > v + t and the
+ * high half, r - v + t - 1 >= 2t, stays non-negative: no false dark bit.)  "Nine contiguous ring pixels all
+ * brighter, or all darker" is then a bitwise AND over nine consecutive X words read off the two sign bits:
+ * 16 three-input ANDs give the runs of 3, 16 more the runs of 9 (gfx950 v_bitop3_b32), an OR tree merges the 16
+ * arcs.  Under half the instructions of the exact score, which only the few percent of pixels that pass need. */
+__device__ __forceinline__ bool fast_is_corner_ld(const uint8_t *c, int ld, uint32_t tt) {
+    /* row pointers from the top-left corner of the 7x7 window: every LDS offset is a non-negative immediate */
+    const uint8_t *q0 = c - 3 * ld - 3, *q1 = q0 + ld, *q2 = q0 + 2 * ld, *q3 = q0 + 3 * ld, *q4 = q0 + 4 * ld, *q5 = q0 + 5 * ld,
+                  *q6 = q0 + 6 * ld;
+    uint32_t r[16];
+    r[0] = q6[3];
+    r[1] = q6[4];
+    r[2] = q5[5];
+    r[3] = q4[6];
+    r[4] = q3[6];
+    r[5] = q2[6];
+    r[6] = q1[5];
+    r[7] = q0[4];
+    r[8] = q0[3];
+    r[9] = q0[2];
+    r[10] = q1[1];
+    r[11] = q2[0];
+    r[12] = q3[0];
+    r[13] = q4[0];
+    r[14] = q5[1];
+    r[15] = q6[2];
+    uint32_t V = tt + (uint32_t)__mul24((int)q3[3], -65535);
+    asm volatile("" : "+v"(V)); /* opaque: keeps X[k] a single mad (the compiler would re-associate into (r - v) * 65535 + tt) */
+    uint32_t sg[16], t3[16], t9[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) sg[k] = __umul24(r[k], 65535u) + V;
+#pragma unroll
+    for (int k = 0; k < 16; k++) t3[k] = sg[k] & sg[(k + 1) & 15] & sg[(k + 2) & 15];
+#pragma unroll
+    for (int k = 0; k < 16; k++) t9[k] = t3[k] & t3[(k + 3) & 15] & t3[(k + 6) & 15];
+    const uint32_t o0 = t9[0] | t9[1] | t9[2], o1 = t9[3] | t9[4] | t9[5], o2 = t9[6] | t9[7] | t9[8], o3 = t9[9] | t9[10] | t9[11],
+                   o4 = t9[12] | t9[13] | t9[14];
+    return (((o0 | o1 | o2) | (o3 | o4 | t9[15])) & 0x80008000u) != 0;
+}
+
+/* ONE WAVEFRONT per (cell, frame): a 64-thread workgroup, LDS tiles sized to the largest cell of the current
+ * geometry (about 4 KB at 640x480), ROI staged as aligned dwords.  No cross-wave barrier, no workgroup scan.
+ *   pass A  corner test at minThFAST of the detection zone in dense 64-pixel row-major chunks; the pixels that
+ *           pass (a few percent) are appended, in order, to an LDS queue by ballot/popcount prefix;
+ *   pass S  exact cornerScore of the queued pixels only, 64 per step;
+ *   pass B  3x3 non-maximum suppression of the queued pixels, flags kept / kept-and->=iniThFAST written back
+ *           into the queue entry;
  *   pass C  ordered emission of the queue entries selected by the per-cell threshold fallback. */
 __global__ __launch_bounds__(64) void k_fast_cells_wave(OrbGeom g, const uint8_t *pyr, const CellDesc *cells, uint32_t *slab,
                                                         int32_t *cell_cnt, int ld, int lh) {
@@ -250,6 +295,7 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(OrbGeom g, const uint8_t
     const float inv_iw = 1.0f / (float)(iw > 0 ? iw : 1);
     const int nch = (n_in + 63) >> 6;
     const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const uint32_t tt = (uint32_t)g.min_th * 0x00010001u;
     /* pass A */
     int nq = 0;
     for (int ch = 0; ch < nch; ch++) {
@@ -260,15 +306,22 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(OrbGeom g, const uint8_t
             const int yy = (int)(((float)i + 0.5f) * inv_iw);
             x = i - __mul24(yy, iw) + 3 + ox;
             y = yy + 3;
-            const int pos = __mul24(y, ld) + x; /* 24-bit multiplies: full rate, unlike v_mul_lo_u32 */
-            const uint8_t *c = s_px + pos;
-            const int sc = fast_score16_ld(c, (int)c[0], ld);
-            hit = sc >= g.min_th;
-            if (hit) s_sc[pos] = (uint8_t)sc;
+            hit = fast_is_corner_ld(s_px + __mul24(y, ld) + x, ld, tt);
         }
         const uint64_t m = __ballot(hit);
         if (hit) s_q[nq + __popcll(m & lt)] = (uint16_t)(y << 7 | x);
         nq += __popcll(m);
+    }
+    __syncthreads();
+    /* pass S */
+#pragma unroll 1
+    for (int j0 = 0; j0 < nq; j0 += 64) {
+        const int j = j0 + lane;
+        if (j < nq) {
+            const int e = s_q[j];
+            const int pos = __mul24(e >> 7, ld) + (e & 127);
+            s_sc[pos] = (uint8_t)fast_score16_ld(s_px + pos, (int)s_px[pos], ld);
+        }
     }
     __syncthreads();
     /* pass B */

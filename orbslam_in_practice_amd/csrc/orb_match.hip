@@ -134,6 +134,11 @@ __device__ __forceinline__ uint32_t f2_order_key(const OrbKeyPoint &kp, int j, b
  * variant) so that the sorted insert works on single registers; it is widened to the 64-bit format of phase 2
  * on the way out.  Used whenever the slab capacity allows (cap <= 2048, resp. <= 65536). */
 #define MK_TILE 512
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 #define MK_TOP 8 /* keys kept per query; phase 2 rescans only if fewer than two of them are still allowed */
 template <bool KEY32>
 __global__ __launch_bounds__(256) void k_match_knn(MatchArgs A) {
@@ -206,7 +211,14 @@ __global__ __launch_bounds__(256) void k_match_knn(MatchArgs A) {
                     key = cand ? (((uint32_t)d << (brute ? 16 : 23)) | ord) : KNONE;
                 else
                     key = cand ? (key_t)(((uint64_t)(uint32_t)d << 32) | ord) : KNONE;
-                if (key < bk[MK_TOP - 1]) { /* rare once the list has warmed up: sorted insert (keys are unique) */
+                if (KEY32) {
+                    /* branch-free sorted insert: with a[k-1] <= a[k], the new a[k] is median(a[k-1], key, a[k])
+                       (one v_med3_u32 each) -- a no-op for key = KNONE */
+#pragma unroll
+                    for (int k = MK_TOP - 1; k > 0; k--)
+                        bk[k] = (key_t)umed3((uint32_t)bk[k - 1], (uint32_t)key, (uint32_t)bk[k]);
+                    bk[0] = key < bk[0] ? key : bk[0];
+                } else if (key < bk[MK_TOP - 1]) { /* rare once the list has warmed up (keys are unique) */
 #pragma unroll
                     for (int k = MK_TOP - 1; k > 0; k--) bk[k] = key < bk[k - 1] ? bk[k - 1] : (key < bk[k] ? key : bk[k]);
                     bk[0] = key < bk[0] ? key : bk[0];
