@@ -119,6 +119,8 @@ void *orb_matcher_stream(OrbMatcher *m);
 /* same hook for the matcher: duration in ms of the last orb_match_batch_device kernel */
 int orb_matcher_set_profiling(OrbMatcher *m, int enable);
 int orb_matcher_get_ms(OrbMatcher *m, float *ms);
+/* the same average per kernel: ms2[0] = phase 1 (all-candidates top-8 scan), ms2[1] = phase 2 (greedy resolve) */
+int orb_matcher_get_stage_ms(OrbMatcher *m, float *ms2);
 int orb_matcher_synchronize(OrbMatcher *m);
 
 /* brute-force Hamming 2-NN (north_star): for every row of d1[n1*32] the best and second

@@ -263,7 +263,8 @@ __global__ __launch_bounds__(64) void k_match_init(MatchArgs A) {
     int32_t *s_m12 = (int32_t *)(s_ang + A.cap);   /* vnMatches12, kept in LDS: no global store inside the serial loop */
     uint16_t *s_md = (uint16_t *)(s_m12 + A.cap);  /* 0xFFFF = INT_MAX */
     uint8_t *s_bin = (uint8_t *)(s_md + A.cap);    /* rotation bin of each i1 */
-    uint4 *s_desc = (uint4 *)(smem + (((size_t)A.cap * 27 + 15) & ~(size_t)15)); /* optional: F2 descriptors */
+    int32_t *s_stamp = (int32_t *)(smem + (((size_t)A.cap * 27 + 15) & ~(size_t)15)); /* speculation stamps, one per F2 keypoint */
+    uint4 *s_desc = (uint4 *)(smem + (((size_t)A.cap * 27 + 15) & ~(size_t)15) + (((size_t)A.cap * 4 + 15) & ~(size_t)15)); /* optional: F2 descriptors */
     __shared__ int s_hist[HISTO_LENGTH];
     int32_t *m12 = s_m12;
     uint8_t *bins = s_bin;
@@ -280,6 +281,7 @@ __global__ __launch_bounds__(64) void k_match_init(MatchArgs A) {
         s_ord[j] = ord;
         s_m21[j] = -1;
         s_md[j] = 0xFFFF;
+        s_stamp[j] = 0x7FFFFFFF;
     }
     for (int i = lane; i < n1; i += 64) {
         m12[i] = -1;
@@ -293,7 +295,13 @@ __global__ __launch_bounds__(64) void k_match_init(MatchArgs A) {
     const float factor = HISTO_LENGTH / 360.0f;
     const ulonglong2 *knn = A.knn + (size_t)pair * A.cap * (MK_TOP / 2);
     for (int base = 0; base < n1; base += 64) {
-      /* prefetch the phase-1 result of 64 queries (one per lane), then walk them in order */
+      /* The phase-1 result of 64 queries, one per lane.  The greedy loop of the reference is sequential in i1,
+       * but query i1 only READS vMatchedDistance of the few candidates it inspects and only WRITES the state of
+       * the one F2 keypoint it matches, so the chunk is resolved in speculative rounds: every pending lane
+       * decides from the current state; a lane is valid if no earlier pending lane that accepts a match writes
+       * into its read set (LDS stamp array, atomicMin of the lane id); the valid prefix commits -- its writes
+       * are to distinct F2 keypoints, hence order-free -- and the first invalid lane opens the next round.
+       * Results are identical to the sequential walk; a round retires ~15 queries instead of one. */
       ulonglong2 mk[MK_TOP / 2];
 #pragma unroll
       for (int k = 0; k < MK_TOP / 2; k++) mk[k] = make_ulonglong2(~0ull, ~0ull);
@@ -303,23 +311,19 @@ __global__ __launch_bounds__(64) void k_match_init(MatchArgs A) {
           for (int k = 0; k < MK_TOP / 2; k++) mk[k] = knn[(size_t)(base + lane) * (MK_TOP / 2) + k];
           ang1 = k1[base + lane].angle;
       }
-      const int nchunk = min(64, n1 - base);
-      for (int t = 0; t < nchunk; t++) {
-        const int i1 = base + t;
-        /* t is wave-uniform: v_readlane (scalar result) instead of an LDS-crossbar shuffle */
-        uint64_t c[MK_TOP];
-        c[0] = rdlane64(mk[0].x, t);
-        if (c[0] == ~0ull) continue; /* no candidate at all (or octave > 0): nothing can match, no state change */
-        c[1] = rdlane64(mk[0].y, t);
+      uint64_t c[MK_TOP];
 #pragma unroll
-        for (int k = 1; k < MK_TOP / 2; k++) {
-            c[2 * k] = rdlane64(mk[k].x, t);
-            c[2 * k + 1] = rdlane64(mk[k].y, t);
-        }
-        const float angle1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ang1), t));
+      for (int k = 0; k < MK_TOP / 2; k++) {
+          c[2 * k] = mk[k].x;
+          c[2 * k + 1] = mk[k].y;
+      }
+      const int nchunk = min(64, n1 - base);
+      int done = 0;
+      while (done < nchunk) {
+        const bool act = lane >= done && lane < nchunk;
+        /* ---- speculative decision of every pending query (the fast path of the sequential walk) ---- */
         /* the filtered candidate set (:49-50) is a subset of the unfiltered one, so its two smallest keys are
-           the first two ALLOWED entries of the sorted unfiltered list -- if they show up within the top MK_TOP.
-           The vMatchedDistance look-ups are independent LDS reads (issued together). */
+           the first two ALLOWED entries of the sorted unfiltered list -- if they show up within the top MK_TOP */
         int mdv[MK_TOP];
 #pragma unroll
         for (int k = 0; k < MK_TOP; k++) {
@@ -329,27 +333,66 @@ __global__ __launch_bounds__(64) void k_match_init(MatchArgs A) {
         }
         uint64_t gKey = ~0ull;
         int bestDist2 = 0x7FFFFFFF;
-        int found = 0;
+        int found = 0, n_insp = MK_TOP;
         bool complete = false; /* the list is the whole candidate set */
 #pragma unroll
         for (int k = 0; k < MK_TOP; k++) {
-            if (c[k] == ~0ull) {
-                complete = true;
-                break;
-            }
-            const int dk = (int)(c[k] >> 32);
-            if (!(mdv[k] <= dk)) {
-                if (found == 0)
-                    gKey = c[k];
-                else if (found == 1)
-                    bestDist2 = dk;
-                found++;
-                if (found == 2) break;
+            if (found < 2 && !complete) {
+                if (c[k] == ~0ull) {
+                    complete = true;
+                    n_insp = k;
+                } else {
+                    const int dk = (int)(c[k] >> 32);
+                    if (!(mdv[k] <= dk)) {
+                        if (found == 0)
+                            gKey = c[k];
+                        else
+                            bestDist2 = dk;
+                        found++;
+                        if (found == 2) n_insp = k + 1;
+                    }
+                }
             }
         }
-        const bool fast = found == 2 || complete;
-        if (fast) {
-        } else {
+        const bool slow = act && !(found == 2 || complete); /* needs the full rescan: resolved alone, below */
+        const int bestDist = (int)(gKey >> 32);
+        const int W = (int)(gKey & 0xFFFFu);
+        const bool accept = act && !slow && gKey != ~0ull && bestDist <= TH_LOW && (float)bestDist < (float)bestDist2 * A.nnratio;
+        if (accept) atomicMin(&s_stamp[W], lane);
+        __syncthreads();
+        bool conflict = false;
+        if (act && !slow) {
+#pragma unroll
+            for (int k = 0; k < MK_TOP; k++)
+                if (k < n_insp) conflict = conflict || s_stamp[(int)(c[k] & 0xFFFFu)] < lane;
+        }
+        const uint64_t badm = __ballot(act && (conflict || slow));
+        const int first_bad = badm ? (int)__builtin_ctzll(badm) : 64;
+        __syncthreads();
+        if (accept) s_stamp[W] = 0x7FFFFFFF; /* every stamp of this round is cleared again */
+        if (accept && lane < first_bad) {
+            const int i1 = base + lane;
+            const int old = s_m21[W];
+            if (old >= 0) m12[old] = -1;
+            m12[i1] = W;
+            s_m21[W] = i1;
+            s_md[W] = (uint16_t)bestDist;
+            if (A.check_ori) {
+                float rot = ang1 - s_ang[W];
+                if (rot < 0.0f) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                bins[i1] = (uint8_t)bin;
+                atomicAdd(&s_hist[bin], 1);
+            }
+        }
+        __syncthreads();
+        done = min(first_bad, nchunk);
+        if (done < nchunk && ((__ballot(slow) >> done) & 1ull)) {
+        /* ---- the rare query whose top MK_TOP list ran out of allowed entries: full rescan, wave-wide ---- */
+        const int t = done;
+        const int i1 = base + t;
+        const float angle1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ang1), t));
         const OrbKeyPoint kp1s = k1[i1];
         float px = kp1s.x, py = kp1s.y;
         if (A.prev_xy) {
@@ -386,22 +429,21 @@ __global__ __launch_bounds__(64) void k_match_init(MatchArgs A) {
                 }
             }
         }
-        gKey = wave_min_u64(bestKey);
-        const int alt = (bestKey == gKey) ? second : (bestKey == ~0ull ? 0x7FFFFFFF : (int)(bestKey >> 32));
-        bestDist2 = wave_min_i32(alt);
-        }
-        if (gKey != ~0ull) {
-            const int bestDist = (int)(gKey >> 32);
-            const int bestIdx2 = (int)(gKey & 0xFFFFu);
-            if (bestDist <= TH_LOW && (float)bestDist < (float)bestDist2 * A.nnratio) {
+        const uint64_t sKey = wave_min_u64(bestKey);
+        const int alt = (bestKey == sKey) ? second : (bestKey == ~0ull ? 0x7FFFFFFF : (int)(bestKey >> 32));
+        const int sDist2 = wave_min_i32(alt);
+        if (sKey != ~0ull) {
+            const int sDist = (int)(sKey >> 32);
+            const int sIdx2 = (int)(sKey & 0xFFFFu);
+            if (sDist <= TH_LOW && (float)sDist < (float)sDist2 * A.nnratio) {
                 if (lane == 0) {
-                    const int old = s_m21[bestIdx2];
+                    const int old = s_m21[sIdx2];
                     if (old >= 0) m12[old] = -1;
-                    m12[i1] = bestIdx2;
-                    s_m21[bestIdx2] = i1;
-                    s_md[bestIdx2] = (uint16_t)bestDist;
+                    m12[i1] = sIdx2;
+                    s_m21[sIdx2] = i1;
+                    s_md[sIdx2] = (uint16_t)sDist;
                     if (A.check_ori) {
-                        float rot = angle1 - s_ang[bestIdx2];
+                        float rot = angle1 - s_ang[sIdx2];
                         if (rot < 0.0f) rot += 360.0f;
                         int bin = (int)roundf(rot * factor);
                         if (bin == HISTO_LENGTH) bin = 0;
@@ -411,7 +453,9 @@ __global__ __launch_bounds__(64) void k_match_init(MatchArgs A) {
                 }
             }
         }
-        __syncthreads(); /* lane 0's LDS updates before the next query (single-wave workgroup) */
+        __syncthreads(); /* lane 0's LDS updates before the next round (single-wave workgroup) */
+        done++;
+        }
       }
     }
     /* nmatches == number of i1 with m12 >= 0 (every accept adds one and every steal removes one) */
@@ -493,7 +537,7 @@ struct OrbMatcher {
     uint16_t *d_best = nullptr, *d_second = nullptr;
     bool profile = false;
     static const int kProfRing = 64;
-    hipEvent_t ev[64][2] = {};
+    hipEvent_t ev[64][3] = {}; /* start, end, between phase 1 (knn) and phase 2 (resolve) */
     long prof_calls = 0;
 };
 
@@ -541,7 +585,7 @@ extern "C" void orb_matcher_destroy(OrbMatcher *m) {
     (void)hipFree(m->d_best);
     (void)hipFree(m->d_second);
     for (int r = 0; r < OrbMatcher::kProfRing; r++)
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < 3; i++)
             if (m->ev[r][i]) (void)hipEventDestroy(m->ev[r][i]);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
@@ -553,7 +597,7 @@ extern "C" int orb_matcher_set_profiling(OrbMatcher *m, int enable) {
     MCHK(hipSetDevice(m->device));
     if (enable && !m->ev[0][0])
         for (int r = 0; r < OrbMatcher::kProfRing; r++)
-            for (int i = 0; i < 2; i++) MCHK(hipEventCreate(&m->ev[r][i]));
+            for (int i = 0; i < 3; i++) MCHK(hipEventCreate(&m->ev[r][i]));
     m->profile = enable != 0;
     m->prof_calls = 0;
     return ORB_OK;
@@ -569,6 +613,23 @@ extern "C" int orb_matcher_get_ms(OrbMatcher *m, float *ms) {
         MCHK(hipEventSynchronize(m->ev[r][1]));
         MCHK(hipEventElapsedTime(&t, m->ev[r][0], m->ev[r][1]));
         *ms += t / n;
+    }
+    m->prof_calls = 0;
+    return ORB_OK;
+}
+/* the same average split into the two kernels: ms2[0] = phase 1 (k_match_knn), ms2[1] = phase 2 (k_match_init) */
+extern "C" int orb_matcher_get_stage_ms(OrbMatcher *m, float *ms2) {
+    if (!m || !ms2 || !m->ev[0][0] || m->prof_calls == 0) return ORB_E_INVALID;
+    MCHK(hipSetDevice(m->device));
+    const int n = (int)(m->prof_calls < OrbMatcher::kProfRing ? m->prof_calls : OrbMatcher::kProfRing);
+    ms2[0] = ms2[1] = 0.f;
+    for (int r = 0; r < n; r++) {
+        float t = 0.f;
+        MCHK(hipEventSynchronize(m->ev[r][1]));
+        MCHK(hipEventElapsedTime(&t, m->ev[r][0], m->ev[r][2]));
+        ms2[0] += t / n;
+        MCHK(hipEventElapsedTime(&t, m->ev[r][2], m->ev[r][1]));
+        ms2[1] += t / n;
     }
     m->prof_calls = 0;
     return ORB_OK;
@@ -641,9 +702,9 @@ extern "C" int orb_hamming_knn2(OrbMatcher *m, const uint8_t *d1, int n1, const 
     return ORB_OK;
 }
 
-static size_t match_lds_bytes(int cap) { return (((size_t)cap * 27 + 15) & ~(size_t)15) + 64; }
+static size_t match_lds_bytes(int cap) { return (((size_t)cap * 27 + 15) & ~(size_t)15) + (((size_t)cap * 4 + 15) & ~(size_t)15) + 64; }
 
-static int launch_match(const MatchArgs &A_in, int n_pairs, hipStream_t st) {
+static int launch_match(const MatchArgs &A_in, int n_pairs, hipStream_t st, hipEvent_t mid = nullptr) {
     MatchArgs A = A_in;
     size_t lds = match_lds_bytes(A.cap);
     A.desc_in_lds = (lds + (size_t)A.cap * 32 <= 96 * 1024) ? 1 : 0; /* keeps >= 1 workgroup per CU resident */
@@ -662,6 +723,7 @@ static int launch_match(const MatchArgs &A_in, int n_pairs, hipStream_t st) {
     else
         hipLaunchKernelGGL(k_match_knn<false>, dim3((A.cap + 255) / 256, n_pairs), dim3(256), 0, st, A);
     MCHK(hipGetLastError());
+    if (mid) MCHK(hipEventRecord(mid, st));
     hipLaunchKernelGGL(k_match_init, dim3(n_pairs), dim3(64), lds, st, A);
     MCHK(hipGetLastError());
     return ORB_OK;
@@ -751,7 +813,7 @@ extern "C" int orb_match_batch_device(OrbMatcher *m, const OrbKeyPoint *d_kps, c
     hipStream_t st = stream ? (hipStream_t)stream : m->stream;
     hipEvent_t *ev = m->ev[m->prof_calls % OrbMatcher::kProfRing];
     if (m->profile) MCHK(hipEventRecord(ev[0], st));
-    int rc = launch_match(A, n_pairs, st);
+    int rc = launch_match(A, n_pairs, st, m->profile ? ev[2] : nullptr);
     if (m->profile) {
         MCHK(hipEventRecord(ev[1], st));
         m->prof_calls++;

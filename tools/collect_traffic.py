@@ -19,12 +19,12 @@ import json
 import sys
 
 STAGE = {"k_copy_level0": "pyramid", "k_resize": "pyramid", "k_fast_cells": "fast", "k_fast_cells_wave": "fast", "k_quadtree": "quadtree",
-         "k_blur": "blur", "k_describe": "describe", "k_match_knn": "match", "k_match_init": "match"}
-LAUNCHES_PER_STEP = {"pyramid": 1, "fast": 1, "quadtree": 1, "blur": 1, "describe": 1, "match": 1}
+         "k_blur": "blur", "k_describe": "describe", "k_match_knn": "match_knn", "k_match_init": "match_resolve"}
+LAUNCHES_PER_STEP = {"pyramid": 1, "fast": 1, "quadtree": 1, "blur": 1, "describe": 1, "match_knn": 1, "match_resolve": 1}
 
 
 def load(d, counter):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    f = (glob.glob(d + "/*counter_collection.csv") + glob.glob(d + "/*/*counter_collection.csv"))[0]
     tot = collections.defaultdict(float)
     calls = collections.Counter()
     for r in csv.DictReader(open(f)):
@@ -33,7 +33,7 @@ def load(d, counter):
         name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
         if name in STAGE:
             tot[STAGE[name]] += float(r["Counter_Value"])
-            if name in ("k_copy_level0", "k_fast_cells", "k_fast_cells_wave", "k_quadtree", "k_blur", "k_describe", "k_match_init"):
+            if name in ("k_copy_level0", "k_fast_cells", "k_fast_cells_wave", "k_quadtree", "k_blur", "k_describe", "k_match_knn", "k_match_init"):
                 calls[STAGE[name]] += 1
     return tot, calls
 
