@@ -69,3 +69,40 @@ def test_host_helpers(matcher, oracle):
     for _ in range(50):
         h = rng.integers(0, 40, 30).astype(np.int32)
         assert matcher.ComputeThreeMaxima(h) == oracle.compute_three_maxima(h)
+
+
+@pytest.mark.parametrize("n1,n2,nproto,flip,window", [(900, 60, 12, 3, -1), (900, 60, 12, 3, 1000), (700, 700, 25, 6, -1),
+                                                       (1500, 200, 5, 10, 80), (64, 3, 1, 20, -1), (2000, 2000, 40, 4, 100)])
+def test_search_for_initialization_contention(oracle, n1, n2, nproto, flip, window):
+    """Many queries compete for few F2 keypoints: descriptors are a handful of prototypes with a few random bit
+    flips, so almost every query's candidate list overlaps its neighbours' -- matches get stolen, vMatchedDistance
+    filters whole top-8 lists (the full-rescan path) and the speculative rounds of the resolve kernel conflict all
+    the time.  Greedy order matters here, so any deviation from the sequential walk shows up."""
+    import orbslam_in_practice_amd as oa
+    rng = np.random.default_rng(n1 * 7 + n2 + nproto)
+    proto = rng.integers(0, 256, (nproto, 32), dtype=np.uint8)
+
+    def descs(n):
+        d = proto[rng.integers(0, nproto, n)].copy()
+        for i in range(n):
+            for b in rng.integers(0, 256, rng.integers(0, flip + 1)):
+                d[i, b >> 3] ^= np.uint8(1 << (b & 7))
+        return d
+
+    def kps(n):
+        kp = np.zeros(n, oa.KP_DTYPE)
+        kp["x"], kp["y"] = rng.uniform(20, 620, n), rng.uniform(20, 460, n)
+        kp["angle"] = rng.uniform(0, 360, n)
+        kp["octave"] = 0
+        return kp
+
+    b = (0.0, 640.0, 0.0, 480.0)
+    k1, k2, d1, d2 = kps(n1), kps(n2), descs(n1), descs(n2)
+    m = oa.ORBmatcher(0.9, True, max_keypoints=2048)
+    for ratio_m in (m,):
+        prev = np.stack([k1["x"], k1["y"]], axis=1).astype(np.float32).copy()
+        on, om12, opm = oracle.search_for_initialization(k1, d1, k2, d2, b, prev.copy(), window, 0.9, True)
+        gn, gm12 = ratio_m.SearchForInitialization(oa.FrameFeatures(k1, d1, b), oa.FrameFeatures(k2, d2, b), prev, window)
+        assert gn == on and np.array_equal(gm12, om12) and np.array_equal(prev, opm)
+    assert on > 0 or nproto == 1  # (one prototype, 20 flips: every best/second pair fails the ratio test)
+    m.close()
