@@ -18,6 +18,7 @@
  * whose score is below iniTh can never beat a pixel whose score is >= iniTh.
  */
 #include "orb_common.h"
+#include <cstdlib>
 
 #define FT_LD 68 /* LDS row pitch */
 
@@ -263,8 +264,9 @@ __device__ __forceinline__ bool fast_is_corner_ld(const uint8_t *c, int ld, uint
 
 /* ONE WAVEFRONT per (cell, frame): a 64-thread workgroup, LDS tiles sized to the largest cell of the current
  * geometry (about 4 KB at 640x480), ROI staged as aligned dwords.  No cross-wave barrier, no workgroup scan.
- *   pass A  corner test at minThFAST of the detection zone in dense 64-pixel row-major chunks; the pixels that
- *           pass (a few percent) are appended, in order, to an LDS queue by ballot/popcount prefix;
+ *   pass A0 compass pre-test (4 ring pixels) of the detection zone in dense 64-pixel row-major chunks; survivors
+ *           (about a quarter) are appended, in order, to an LDS queue by ballot/popcount prefix;
+ *   pass A  full corner test at minThFAST of the queued pixels, queue compacted in place (about a tenth remain);
  *   pass S  exact cornerScore of the queued pixels only, 64 per step;
  *   pass B  3x3 non-maximum suppression of the queued pixels, flags kept / kept-and->=iniThFAST written back
  *           into the queue entry;
@@ -296,8 +298,11 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(OrbGeom g, const uint8_t
     const int nch = (n_in + 63) >> 6;
     const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const uint32_t tt = (uint32_t)g.min_th * 0x00010001u;
-    /* pass A */
-    int nq = 0;
+    /* pass A0: compass pre-test of every pixel.  A run of 9 on the 16-ring always contains two ADJACENT compass
+       points (ring positions 0, 4, 8, 12), and "two adjacent of a 4-cycle" is (N|S)&(E|W): with the sign-bit words
+       X[k] of fast_is_corner_ld this is two logic ops for both polarities at once.  About a quarter of the pixels
+       of a textured image survive; they are queued in row-major order. */
+    int nq0 = 0;
     for (int ch = 0; ch < nch; ch++) {
         const int i = ch * 64 + lane;
         bool hit = false;
@@ -306,10 +311,34 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(OrbGeom g, const uint8_t
             const int yy = (int)(((float)i + 0.5f) * inv_iw);
             x = i - __mul24(yy, iw) + 3 + ox;
             y = yy + 3;
-            hit = fast_is_corner_ld(s_px + __mul24(y, ld) + x, ld, tt);
+            const uint8_t *c = s_px + __mul24(y, ld) + x - 3; /* centre at c[3] */
+            const uint8_t *up = c - 3 * ld, *dn = c + 3 * ld;
+            uint32_t V = tt + (uint32_t)__mul24((int)c[3], -65535);
+            asm volatile("" : "+v"(V));
+            const uint32_t s0 = __umul24((uint32_t)dn[3], 65535u) + V, s4 = __umul24((uint32_t)c[6], 65535u) + V,
+                           s8 = __umul24((uint32_t)up[3], 65535u) + V, s12 = __umul24((uint32_t)c[0], 65535u) + V;
+            hit = (((s0 | s8) & (s4 | s12)) & 0x80008000u) != 0;
         }
         const uint64_t m = __ballot(hit);
-        if (hit) s_q[nq + __popcll(m & lt)] = (uint16_t)(y << 7 | x);
+        if (hit) s_q[nq0 + __popcll(m & lt)] = (uint16_t)(y << 7 | x);
+        nq0 += __popcll(m);
+    }
+    __syncthreads();
+    /* pass A: the full corner test on the queued pixels, the queue compacted in place (a wave reads its 64
+       entries before it writes at most as many at or below them) */
+    int nq = 0;
+#pragma unroll 1
+    for (int j0 = 0; j0 < nq0; j0 += 64) {
+        const int j = j0 + lane;
+        bool hit = false;
+        int e = 0;
+        if (j < nq0) {
+            e = s_q[j];
+            hit = fast_is_corner_ld(s_px + __mul24(e >> 7, ld) + (e & 127), ld, tt);
+        }
+        __syncthreads();
+        const uint64_t m = __ballot(hit);
+        if (hit) s_q[nq + __popcll(m & lt)] = (uint16_t)e;
         nq += __popcll(m);
     }
     __syncthreads();
