@@ -203,10 +203,9 @@ def main():
             self.nm = torch.zeros((B,), dtype=torch.int32, device=dev)
             self.extracted = torch.cuda.Event()
             self.matched = torch.cuda.Event()
+            self.gathered = torch.cuda.Event()
 
     slabs = [Slab(), Slab()]
-    if world > 1:
-        nsplit = 1  # the exchange orders the two halves anyway
     exts = [ext, ext2][:nsplit]
     matchers = [matcher, matcher2][:nsplit]
     sAs = [torch.cuda.Stream(device=dev) for _ in range(nsplit)]
@@ -237,11 +236,16 @@ def main():
                 for ev in sl.extracted:
                     sB.wait_event(ev)  # pair (k, k+1) may straddle the halves
                 if world > 1:
-                    # the one exchange step of the path: fixed-capacity feature slabs over xGMI (RCCL all-gather).
-                    # It lives on the MATCH stream, so the next batch's extraction (stream A) overlaps it.
-                    all_gather_flat(sl.kps, sl.k_loc)
-                    all_gather_flat(sl.desc, sl.d_loc)
-                    all_gather_flat(sl.cnt, sl.c_loc)
+                    # the one exchange step of the path: fixed-capacity feature slabs over xGMI (RCCL all-gather),
+                    # once per step for the rank's whole block.  It lives on lane 0's MATCH stream, so the next
+                    # batch's extraction (streams A) overlaps it; the other lane's match waits for its event.
+                    if hh == 0:
+                        all_gather_flat(sl.kps, sl.k_loc)
+                        all_gather_flat(sl.desc, sl.d_loc)
+                        all_gather_flat(sl.cnt, sl.c_loc)
+                        sl.gathered.record(sB)
+                    else:
+                        sB.wait_event(sl.gathered)
                 p0 = hh * Bh
                 matchers[hh].match_batch_device(sl.kps.data_ptr(), sl.desc.data_ptr(), sl.cnt.data_ptr(), cap,
                                                 pa.data_ptr() + p0 * 4, pb.data_ptr() + p0 * 4, Bh, bounds, args.window,
