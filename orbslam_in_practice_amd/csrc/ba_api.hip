@@ -59,6 +59,7 @@ struct BAWin {
     int64_t A, Linv; /* dense reduced system (np x np) and inverse diagonal blocks of its Cholesky factor */
     /* ints */
     int64_t cam, pt, pt_start, cam_start, cam_edges, slot, blk_row, blk_col, blk_diag, blk_mirror, blk_upper, blk_rowid, con_start, con_e1, con_e2;
+    int64_t ch_first, ch_last; /* Cholesky envelope per 16-row tile: first tile column of tile row i (non-decreasing), last tile row that reaches tile column k */
     /* bytes */
     int64_t flags; /* per edge: bit0 active, bit1 robust */
 };
@@ -282,7 +283,11 @@ __device__ bool ba_chol_solve(const BAWin &w, double *D, const int32_t *I, int n
     double *sl = sd + 16 * CH_LD;           /* its inverse, 16 x CH_LD      */
     double *z = sl + 16 * CH_LD;            /* right-hand side / solution   */
     /* ---- assemble the dense matrix from the block-sparse S ---- */
-    for (int i = tid; i < np * np; i += BA_T) A[i] = 0.0;
+    const int32_t *efirst = I + w.ch_first, *elast = I + w.ch_last;
+    for (int r = wave; r < np; r += BA_W) { /* only the envelope [first(tile row) * 16, diagonal tile] is ever read */
+        const int c0 = efirst[r >> 4] * 16, c1 = ((r >> 4) + 1) * 16;
+        for (int c = c0 + lane; c < c1; c += 64) A[(int64_t)r * np + c] = 0.0;
+    }
     if (tid == 0) s.bc[0] = 0.0;
     __syncthreads();
     for (int i = tid; i < w.nnzb * 36; i += BA_T) {
@@ -294,7 +299,7 @@ __device__ bool ba_chol_solve(const BAWin &w, double *D, const int32_t *I, int n
     __syncthreads();
     /* ---- factorisation ---- */
     for (int kb = 0; kb < nb; kb++) {
-        const int m = nb - kb - 1;
+        const int m = elast[kb] - kb; /* tile rows below the diagonal that reach column kb */
         if (tid < 256) sd[(tid >> 4) * CH_LD + (tid & 15)] = A[(int64_t)(kb * 16 + (tid >> 4)) * np + kb * 16 + (tid & 15)];
         __syncthreads();
         if (wave == 0) {
@@ -415,7 +420,7 @@ __device__ bool ba_chol_solve(const BAWin &w, double *D, const int32_t *I, int n
         __syncthreads();
         if (tid < 16) z[kb * 16 + tid] = v;
         __syncthreads();
-        for (int i = (kb + 1) * 16 + tid; i < np; i += BA_T) {
+        for (int i = (kb + 1) * 16 + tid; i < (elast[kb] + 1) * 16; i += BA_T) {
             const double *Ar = A + (int64_t)i * np + kb * 16;
             double acc = 0.0;
 #pragma unroll
@@ -432,7 +437,7 @@ __device__ bool ba_chol_solve(const BAWin &w, double *D, const int32_t *I, int n
         __syncthreads();
         if (tid < 16) z[kb * 16 + tid] = v;
         __syncthreads();
-        for (int j = tid; j < kb * 16; j += BA_T) {
+        for (int j = efirst[kb] * 16 + tid; j < kb * 16; j += BA_T) {
             double acc = 0.0;
 #pragma unroll
             for (int r = 0; r < 16; r++) acc += A[(int64_t)(kb * 16 + r) * np + j] * z[kb * 16 + r];
@@ -1090,7 +1095,7 @@ struct HostWin {
 static int64_t BAWin::*const kInputDFields[] = {&BAWin::poses, &BAWin::pts, &BAWin::obs, &BAWin::info, &BAWin::st};
 static int64_t BAWin::*const kIntFields[] = {&BAWin::cam,     &BAWin::pt,      &BAWin::pt_start, &BAWin::cam_start,
                                              &BAWin::cam_edges, &BAWin::slot,  &BAWin::blk_row,  &BAWin::blk_col,
-                                             &BAWin::blk_diag, &BAWin::blk_mirror, &BAWin::blk_upper, &BAWin::blk_rowid, &BAWin::con_start, &BAWin::con_e1, &BAWin::con_e2};
+                                             &BAWin::blk_diag, &BAWin::blk_mirror, &BAWin::blk_upper, &BAWin::blk_rowid, &BAWin::con_start, &BAWin::con_e1, &BAWin::con_e2, &BAWin::ch_first, &BAWin::ch_last};
 static int64_t BAWin::*const kScratchFields[] = {&BAWin::poses_t, &BAWin::pts_t, &BAWin::err, &BAWin::err_t, &BAWin::W,
                                                  &BAWin::Y,       &BAWin::Hpp,   &BAWin::bp,  &BAWin::Hll,   &BAWin::bl,
                                                  &BAWin::Dinv,    &BAWin::S,     &BAWin::g,   &BAWin::Minv,  &BAWin::x,
@@ -1278,6 +1283,32 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hD, size_t &sc
     w.blk_rowid = allocI(nnzb);
     for (int s1 = 0; s1 < Ncf; s1++)
         for (int bk = brow[s1]; bk < brow[s1 + 1]; bk++) hI[w.blk_rowid + bk] = s1;
+    {
+        /* envelope (skyline) of S in 16 x 16 tiles for the in-kernel Cholesky: fill-in never leaves the region
+           [first(i), i] of each row, and local-BA windows are chain-like (a point is seen by neighbouring
+           keyframes), so the envelope is a band -- at 100 KFs x 5000 points about a fifth of the triangle */
+        const int nbt = (Ncf * 6 + 15) / 16;
+        std::vector<int> first(std::max(nbt, 1), 0), last(std::max(nbt, 1), 0);
+        for (int t = 0; t < nbt; t++) first[t] = t;
+        for (int s1 = 0; s1 < Ncf; s1++) {
+            int mincol = s1; /* lowest block column of this block row (the pattern is symmetric) */
+            for (int bk = brow[s1]; bk < brow[s1 + 1]; bk++) mincol = std::min(mincol, bcol[bk]);
+            const int tc = (mincol * 6) / 16;
+            for (int t = (s1 * 6) / 16; t <= (s1 * 6 + 5) / 16 && t < nbt; t++) first[t] = std::min(first[t], tc);
+        }
+        for (int t = nbt - 2; t >= 0; t--) first[t] = std::min(first[t], first[t + 1]); /* non-decreasing */
+        for (int k = 0; k < nbt; k++) {
+            int l = k;
+            while (l + 1 < nbt && first[l + 1] <= k) l++;
+            last[k] = l;
+        }
+        w.ch_first = allocI(std::max(nbt, 1));
+        w.ch_last = allocI(std::max(nbt, 1));
+        for (int t = 0; t < nbt; t++) {
+            hI[w.ch_first + t] = first[t];
+            hI[w.ch_last + t] = last[t];
+        }
+    }
     {
         std::vector<int> upper;
         for (int i = 0; i < nnzb; i++)
