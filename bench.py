@@ -122,7 +122,7 @@ def main():
     ap.add_argument("--window", type=int, default=-1, help="match window (-1 = brute force; 100 = the reference's "
                     "SearchForInitialization call, src/Tracking.cpp:189)")
     ap.add_argument("--nfeatures", type=int, default=NFEATURES)
-    ap.add_argument("--split", type=int, default=2, help="1 or 2: halves of a batch on separate stream pairs")
+    ap.add_argument("--split", type=int, default=2, help="1..4 launch lanes: equal parts of a batch on separate stream pairs")
     ap.add_argument("--ba-windows", type=int, default=256, help="windows in the local-BA side measurement (0 = skip)")
     args = ap.parse_args()
     W, H = (int(v) for v in args.size.lower().split("x"))
@@ -170,11 +170,10 @@ def main():
     # a second extractor/matcher pair lets the two HALVES of a step's batch run on their own streams: the
     # latency-bound stages of one half (quadtree, match resolution) then overlap the throughput-bound stages of
     # the other (pyramid, FAST, blur)
-    nsplit = max(1, min(args.split, 2))
-    ext2 = matcher2 = None
-    if nsplit == 2:
-        ext2 = oa.ORBextractor(NFEATURES, SCALE, NLEVELS, INI_TH, MIN_TH, max_w=W, max_h=H, max_batch=B, device=local_rank)
-        matcher2 = oa.ORBmatcher(0.9, True, max_keypoints=cap, max_pairs=B, device=local_rank)
+    nsplit = max(1, min(args.split, 4))
+    more_ext = [oa.ORBextractor(NFEATURES, SCALE, NLEVELS, INI_TH, MIN_TH, max_w=W, max_h=H, max_batch=B, device=local_rank)
+                for _ in range(nsplit - 1)]
+    more_match = [oa.ORBmatcher(0.9, True, max_keypoints=cap, max_pairs=B, device=local_rank) for _ in range(nsplit - 1)]
 
     frames = synth.make_stream(1000 + rank, B, W, H)
     d_imgs = torch.from_numpy(frames).to(dev)
@@ -206,8 +205,8 @@ def main():
             self.gathered = torch.cuda.Event()
 
     slabs = [Slab(), Slab()]
-    exts = [ext, ext2][:nsplit]
-    matchers = [matcher, matcher2][:nsplit]
+    exts = [ext] + more_ext
+    matchers = [matcher] + more_match
     sAs = [torch.cuda.Stream(device=dev) for _ in range(nsplit)]
     sBs = [torch.cuda.Stream(device=dev) for _ in range(nsplit)]
     for sl in slabs:

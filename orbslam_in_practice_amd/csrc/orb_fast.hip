@@ -1,15 +1,18 @@
 /*
  * orb_fast.hip -- per-cell FAST-9/16 corner scoring, 3x3 non-max suppression and the two-threshold
  * fallback of ORBextractor::ComputeKeyPointsOctTree (reference src/ORBextractor.cpp:745-786), all
- * cells of all levels of all frames in ONE launch: one 256-thread workgroup per (cell, frame).
+ * cells of all levels of all frames in ONE launch: one WAVEFRONT per (cell, frame)
+ * (k_fast_cells_wave; k_fast_cells, one 256-thread workgroup per cell, remains for geometries whose
+ * cells exceed the wave kernel's tile bookkeeping).
  *
  *   - the cell ROI (<= 65x65 u8, incl. the 3-px rim cv::FAST ignores) is staged in LDS with
- *     row-coalesced loads;
- *   - every interior pixel gets its cornerScore (largest threshold at which it is still a 9/16
- *     corner) from 16 LDS ring reads; "corner at threshold t"  <=>  score >= t, so ONE scoring pass
- *     serves both iniThFAST and minThFAST;
+ *     row-coalesced dword loads;
+ *   - "corner at threshold t"  <=>  cornerScore >= t (the score is the largest threshold at which the
+ *     pixel is still a 9/16 corner), so the detection zone is first filtered at minThFAST -- a compass
+ *     pre-test, then the full sign-bit arc test -- and only the survivors (queued in row-major order in
+ *     LDS) get their exact cornerScore; ONE scoring pass serves both iniThFAST and minThFAST;
  *   - NMS keeps a pixel iff its score is strictly greater than its 8 neighbours INSIDE the cell's
- *     detection zone (scores outside are 0, exactly like cv::FAST on the cell ROI);
+ *     detection zone (scores outside, and of non-corners, are 0, exactly like cv::FAST on the cell ROI);
  *   - if no pixel survives at iniThFAST the cell falls back to minThFAST (per-cell decision);
  *   - survivors are emitted in the reference's order (row-major inside the cell) into the cell's slab
  *     slot with a wavefront ballot/popcount compaction -- no atomics, deterministic order.

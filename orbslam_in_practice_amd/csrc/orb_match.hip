@@ -5,12 +5,17 @@
  *   k_hamming_knn2   brute-force 2-NN (north_star / SURVEY a12): one query descriptor per lane in
  *                    8 VGPRs, the train set streamed through LDS in 1024-descriptor tiles and read
  *                    back as wave-wide broadcasts (conflict free), ties -> lowest index.
- *   k_match_init     ORBmatcher::SearchForInitialization (reference src/ORBmatcher.cpp:9-126) with
- *                    Frame::GetFeaturesInArea (src/Frame.cpp:219-271): ONE wavefront per frame pair.
- *                    The reference loop over i1 carries a dependency (a later i1 may only take an i2
- *                    whose recorded match distance is larger, :49-50), so i1 is walked in order while
- *                    the candidate scan of each i1 is spread over the 64 lanes and finished with a
- *                    wave reduction on (distance, grid order) keys.
+ *   k_match_knn      phase 1 of ORBmatcher::SearchForInitialization (reference src/ORBmatcher.cpp:9-126
+ *                    with Frame::GetFeaturesInArea, src/Frame.cpp:219-271): fully parallel, the 8
+ *                    smallest (distance, grid order, index) keys of every query over all its window
+ *                    candidates, ignoring the greedy filter.
+ *   k_match_init     phase 2: ONE wavefront per frame pair.  The reference loop over i1 carries a
+ *                    dependency (a later i1 may only take an i2 whose recorded match distance is
+ *                    larger, :49-50); the filtered candidate set is a subset of the unfiltered one, so
+ *                    the answer of a query is read off its phase-1 list, and 64 queries at a time are
+ *                    resolved in speculative rounds that commit exactly the prefix the sequential walk
+ *                    would have produced (see the kernel); a query whose list is exhausted is rescanned
+ *                    by the whole wave with a (distance, grid order) min-reduction.
  *
  * Candidate set and order of GetFeaturesInArea without materialising the 64x48 grid: an F2 keypoint is
  * a candidate iff it was assigned to the grid (round((p-min)*inv) inside the grid, src/Frame.cpp:
