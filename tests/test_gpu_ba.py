@@ -157,3 +157,31 @@ def test_ba_cholesky_equals_pcg_many_sizes(oracle):
     assert _rel(a[17]["points"], ref["points"]) < REL
     chol.close()
     pcg.close()
+
+
+@pytest.mark.parametrize("nc,npt,seed", [(24, 600, 1), (60, 2500, 2), (100, 5000, 3)])
+def test_ba_shuffled_camera_order(opt, oracle, nc, npt, seed):
+    """The blocked Cholesky works inside the envelope of S in the caller's camera order.  Shuffling the cameras
+    of a chain-like window turns the band into an irregular pattern (tile rows whose first non-zero column is
+    NOT monotone, envelope close to dense): same estimates as the oracle, camera by camera."""
+    from orbslam_in_practice_amd import synth
+    w = synth.make_ba_window(7000 + seed, nc, npt)
+    rng = np.random.default_rng(seed)
+    perm = np.concatenate([[0], 1 + rng.permutation(nc - 1)])      # new position -> old camera (KF 0 stays first)
+    inv = np.empty(nc, np.int64)
+    inv[perm] = np.arange(nc)
+    ws = dict(w)
+    ws["poses"] = w["poses"][perm].copy()
+    ws["fixed"] = w["fixed"][perm].copy()
+    ws["fixed"][:2] = 1
+    ws["cam_idx"] = inv[w["cam_idx"]].astype(np.int32)
+    for k in ("gt_poses",):
+        if k in w:
+            ws[k] = w[k][perm].copy()
+    ref = oracle.ba_solve(ws, rounds=(5, 10))
+    got = opt.solve_batch([ws], (5, 10))[0]
+    assert got["iterations"] == ref["iterations"]
+    assert np.array_equal(got["outlier"], ref["outlier"])
+    assert _rel(got["points"], ref["points"]) < REL
+    assert _rel(got["poses"][:, 4:], ref["poses"][:, 4:]) < REL
+    assert abs(got["chi2_final"] - ref["chi2_final"]) <= 1e-6 * ref["chi2_final"]
