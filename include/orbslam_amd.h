@@ -145,6 +145,15 @@ int orb_match_init(OrbMatcher *m, const OrbFrameView *f1, const OrbFrameView *f2
                    int32_t *matches12, int window_size, float nnratio, int check_orientation,
                    int32_t *n_matches);
 
+/* Frame::AssignFeaturesToGrid + Frame::GetFeaturesInArea (reference src/Frame.cpp:144-168, 219-271)
+ * for a batch of queries against one frame's keypoints, on the device: queries_xyr[3*q] = (x, y, r),
+ * query_levels[2*q] = (minLevel, maxLevel) or NULL for (-1, -1) (no level filter, as :245 computes it).
+ * out_idx[q*cap + k] receives the indices the reference returns, in its order (grid cell column-major, then
+ * insertion order), -1 padded; out_count[q] the full count (entries beyond cap are dropped).  Host pointers. */
+int orb_features_in_area(OrbMatcher *m, const OrbFrameView *f, const float *queries_xyr, const int32_t *query_levels,
+                         int n_queries, int32_t *out_idx, int cap, int32_t *out_count);
+
+
 /* Batched, device-resident matching of n_pairs frame pairs (pair p: frame a[p] against frame b[p] of
  * the slabs an extractor produced with capacity `cap`): d_kps[n_frames*cap], d_desc[n_frames*cap*32],
  * d_counts[n_frames].  prev_matched is taken to be F1's own keypoint positions (first call of

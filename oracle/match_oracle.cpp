@@ -153,6 +153,19 @@ void orc_hamming_knn2(const uint8_t *d1, int n1, const uint8_t *d2, int n2, int3
 
 /* src/ORBmatcher.cpp:9-126.  window_size < 0: the a12 "brute force" variant -- every i1 (all
  * octaves), candidates = every i2 in ascending order; everything else identical. */
+/* Frame::AssignFeaturesToGrid + Frame::GetFeaturesInArea (src/Frame.cpp:144-168, 219-271) for nq queries
+ * (x, y, r) with level filters; out_idx[q * cap + k] in the reference's order, out_count[q] = full count */
+void orc_features_in_area(const OrcFrameView *F, const float *qxyr, const int32_t *qlevels, int nq, int32_t *out_idx, int cap,
+                          int32_t *out_count) {
+    FrameGrid g(F);
+    for (int q = 0; q < nq; q++) {
+        const int lo = qlevels ? qlevels[2 * q] : -1, hi = qlevels ? qlevels[2 * q + 1] : -1;
+        const std::vector<size_t> v = g.GetFeaturesInArea(qxyr[3 * q], qxyr[3 * q + 1], qxyr[3 * q + 2], lo, hi);
+        out_count[q] = (int32_t)v.size();
+        for (size_t k = 0; k < v.size() && (int)k < cap; k++) out_idx[(size_t)q * cap + k] = (int32_t)v[k];
+    }
+}
+
 int orc_search_for_initialization(const OrcFrameView *F1, const OrcFrameView *F2, float *prev_xy,
                                   int32_t *vnMatches12, int windowSize, float mfNNratio, int mbCheckOrientation,
                                   int clone_mode) {

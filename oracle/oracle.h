@@ -80,6 +80,8 @@ typedef struct OrcFrameView {
 /* clone_mode: 1 = literally clone the whole descriptor Mat per GetDescriptors() call
  * (reference include/Frame.h:39-42), 0 = no clone; results identical, timing differs.
  * window_size < 0 means "infinite window, all octaves, ascending i2" (the a12 variant). */
+void orc_features_in_area(const OrcFrameView *f, const float *qxyr, const int32_t *qlevels, int nq, int32_t *out_idx, int cap,
+                          int32_t *out_count);
 int orc_search_for_initialization(const OrcFrameView *f1, const OrcFrameView *f2, float *prev_matched_xy,
                                   int32_t *matches12, int window_size, float nnratio, int check_ori,
                                   int clone_mode);

@@ -270,6 +270,24 @@ def search_for_initialization(kps1, desc1, kps2, desc2, bounds, prev_matched=Non
     return n, m12, pm
 
 
+def features_in_area(kps, bounds, queries_xyr, levels=None, cap=None):
+    """Frame::GetFeaturesInArea for every query row (x, y, r); levels = (nq, 2) int32 (minLevel, maxLevel) or None
+    for (-1, -1).  Returns a list of int32 index arrays in the reference's order."""
+    v, keep = _view(kps, np.zeros((len(kps), 32), np.uint8), bounds)
+    q = np.ascontiguousarray(queries_xyr, np.float32).reshape(-1, 3)
+    nq = len(q)
+    cap = int(cap if cap is not None else max(len(kps), 1))
+    lv = None if levels is None else np.ascontiguousarray(levels, np.int32).reshape(nq, 2)
+    out = np.full((nq, cap), -1, np.int32)
+    cnt = np.zeros(nq, np.int32)
+    L = lib()
+    L.orc_features_in_area.argtypes = [C.POINTER(FrameView), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    L.orc_features_in_area.restype = None
+    L.orc_features_in_area(C.byref(v), _p(q), _p(lv) if lv is not None else None, nq, _p(out), cap, _p(cnt))
+    del keep
+    return [out[i, :min(cnt[i], cap)].copy() for i in range(nq)], cnt
+
+
 def compute_three_maxima(sizes):
     sizes = np.ascontiguousarray(sizes, np.int32)
     a, b, c = C.c_int32(-1), C.c_int32(-1), C.c_int32(-1)

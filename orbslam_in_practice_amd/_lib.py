@@ -58,7 +58,7 @@ EXPORTS = [
     "orb_last_error", "orb_device_count", "orb_create", "orb_destroy", "orb_get_levels", "orb_get_scale_factor",
     "orb_get_tables", "orb_get_level_sizes", "orb_max_keypoints", "orb_extract", "orb_extract_batch",
     "orb_extract_batch_device", "orb_download_level", "orb_download_candidates", "orb_synchronize", "orb_stream",
-    "orb_set_profiling", "orb_get_stage_ms", "orb_matcher_set_profiling", "orb_matcher_get_ms", "orb_matcher_get_stage_ms",
+    "orb_set_profiling", "orb_get_stage_ms", "orb_matcher_set_profiling", "orb_matcher_get_ms", "orb_matcher_get_stage_ms", "orb_features_in_area",
     "orb_descriptor_distance", "orb_compute_three_maxima", "orb_matcher_create", "orb_matcher_destroy",
     "orb_matcher_stream", "orb_matcher_synchronize", "orb_hamming_knn2", "orb_match_init",
     "orb_match_batch_device", "ba_create", "ba_destroy", "ba_solve", "ba_solve_batch", "ba_pose_optimization", "ba_pose_optimization_batch",
@@ -105,6 +105,7 @@ def lib():
     L.orb_matcher_set_profiling.argtypes = [vp, i32]
     L.orb_matcher_get_ms.argtypes = [vp, vp]
     L.orb_matcher_get_stage_ms.argtypes = [vp, vp]
+    L.orb_features_in_area.argtypes = [vp, vp, vp, vp, i32, vp, i32, vp]
     L.orb_stream.argtypes = [vp]
     L.orb_stream.restype = vp
     L.orb_descriptor_distance.argtypes = [vp, vp]

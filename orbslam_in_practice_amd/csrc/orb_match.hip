@@ -27,6 +27,7 @@
 #include "orb_common.h"
 #include <type_traits>
 
+#include <algorithm>
 #include <cstring>
 #include <string>
 
@@ -514,6 +515,54 @@ __global__ __launch_bounds__(64) void k_match_init(MatchArgs A) {
     if (lane == 0) A.nmatches[pair] = cnt;
 }
 
+/* Frame::AssignFeaturesToGrid + Frame::GetFeaturesInArea (reference src/Frame.cpp:144-168, 219-271) for a batch
+ * of queries against one frame, without materialising the 64 x 48 grid (see the file header: a keypoint is
+ * returned iff it was assigned to the grid, passes the level filter and lies strictly inside the square window;
+ * the reference's order is (cell x, cell y, insertion order) = ascending (cell << 16 | index)).  One wavefront
+ * per query: candidates are collected in index order by ballot compaction, then every candidate's output slot
+ * is its rank among the collected keys. */
+__global__ __launch_bounds__(64) void k_features_in_area(const OrbKeyPoint *kps, int n, float min_x, float max_x, float min_y,
+                                                         float max_y, const float *qxyr, const int32_t *qlevels, int nq,
+                                                         int32_t *out_idx, int cap, int32_t *out_count) {
+    extern __shared__ uint32_t fa_keys[]; /* n entries */
+    const int q = blockIdx.x, lane = threadIdx.x;
+    if (q >= nq) return;
+    const float x = qxyr[3 * q], y = qxyr[3 * q + 1], r = qxyr[3 * q + 2];
+    const int minLevel = qlevels ? qlevels[2 * q] : -1, maxLevel = qlevels ? qlevels[2 * q + 1] : -1;
+    const bool check = (minLevel > 0) || (maxLevel >= 0);
+    const float invW = (float)GRID_COLS / (max_x - min_x), invH = (float)GRID_ROWS / (max_y - min_y);
+    const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int nc = 0;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        const int j = j0 + lane;
+        bool cand = false;
+        uint32_t key = 0;
+        if (j < n) {
+            const OrbKeyPoint kp = kps[j];
+            const int ix = (int)round(((double)kp.x - (double)min_x) * (double)invW);
+            const int iy = (int)round(((double)kp.y - (double)min_y) * (double)invH);
+            cand = ix >= 0 && ix < GRID_COLS && iy >= 0 && iy < GRID_ROWS;
+            if (check) {
+                if (kp.octave < minLevel) cand = false;
+                if (maxLevel >= 0 && kp.octave > maxLevel) cand = false;
+            }
+            cand = cand && fabsf(kp.x - x) < r && fabsf(kp.y - y) < r;
+            key = ((uint32_t)(ix * GRID_ROWS + iy) << 16) | (uint32_t)j;
+        }
+        const uint64_t m = __ballot(cand);
+        if (cand) fa_keys[nc + __popcll(m & lt)] = key;
+        nc += __popcll(m);
+    }
+    __syncthreads();
+    for (int i = lane; i < nc; i += 64) {
+        const uint32_t key = fa_keys[i];
+        int rank = 0;
+        for (int k = 0; k < nc; k++) rank += fa_keys[k] < key ? 1 : 0;
+        if (rank < cap) out_idx[(size_t)q * cap + rank] = (int32_t)(key & 0xFFFFu);
+    }
+    if (lane == 0) out_count[q] = nc;
+}
+
 /* ------------------------------------------------------------------------------------------------ */
 static thread_local std::string m_err;
 #define MCHK(expr)                                                                         \
@@ -782,6 +831,52 @@ extern "C" int orb_match_init(OrbMatcher *m, const OrbFrameView *f1, const OrbFr
     if (prev_matched_xy)
         MCHK(hipMemcpyAsync(prev_matched_xy, m->d_prev_out, (size_t)f1->n * 8, hipMemcpyDeviceToHost, m->stream));
     MCHK(hipStreamSynchronize(m->stream));
+    return ORB_OK;
+}
+
+extern "C" int orb_features_in_area(OrbMatcher *m, const OrbFrameView *f, const float *queries_xyr, const int32_t *query_levels,
+                                    int n_queries, int32_t *out_idx, int cap, int32_t *out_count) {
+    if (!m || !f || f->n < 0 || n_queries < 0 || cap < 0 || (n_queries > 0 && (!queries_xyr || !out_count)) ||
+        (n_queries > 0 && cap > 0 && !out_idx) || (f->n > 0 && !f->kps))
+        return ORB_E_INVALID;
+    if (f->n > m->max_kp || f->n > 65535) return ORB_E_CAPACITY;
+    if (n_queries == 0) return ORB_OK;
+    MCHK(hipSetDevice(m->device));
+    float *d_q = nullptr;
+    int32_t *d_lv = nullptr, *d_out = nullptr, *d_cnt = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(d_q);
+        (void)hipFree(d_lv);
+        (void)hipFree(d_out);
+        (void)hipFree(d_cnt);
+    };
+#define FCHK(e)                                  \
+    do {                                         \
+        hipError_t _e = (e);                     \
+        if (_e != hipSuccess) {                  \
+            m_err = hipGetErrorString(_e);       \
+            cleanup();                           \
+            return ORB_E_HIP;                    \
+        }                                        \
+    } while (0)
+    FCHK(hipMalloc(&d_q, (size_t)n_queries * 12));
+    FCHK(hipMalloc(&d_cnt, (size_t)n_queries * 4));
+    FCHK(hipMalloc(&d_out, std::max<size_t>((size_t)n_queries * cap * 4, 4)));
+    if (query_levels) {
+        FCHK(hipMalloc(&d_lv, (size_t)n_queries * 8));
+        FCHK(hipMemcpyAsync(d_lv, query_levels, (size_t)n_queries * 8, hipMemcpyHostToDevice, m->stream));
+    }
+    FCHK(hipMemcpyAsync(d_q, queries_xyr, (size_t)n_queries * 12, hipMemcpyHostToDevice, m->stream));
+    if (f->n > 0) FCHK(hipMemcpyAsync(m->d_kps, f->kps, (size_t)f->n * sizeof(OrbKeyPoint), hipMemcpyHostToDevice, m->stream));
+    FCHK(hipMemsetAsync(d_out, 0xFF, std::max<size_t>((size_t)n_queries * cap * 4, 4), m->stream));
+    hipLaunchKernelGGL(k_features_in_area, dim3(n_queries), dim3(64), (size_t)std::max(f->n, 1) * 4, m->stream, m->d_kps, f->n,
+                       f->min_x, f->max_x, f->min_y, f->max_y, d_q, d_lv, n_queries, d_out, cap, d_cnt);
+    FCHK(hipGetLastError());
+    if (cap > 0) FCHK(hipMemcpyAsync(out_idx, d_out, (size_t)n_queries * cap * 4, hipMemcpyDeviceToHost, m->stream));
+    FCHK(hipMemcpyAsync(out_count, d_cnt, (size_t)n_queries * 4, hipMemcpyDeviceToHost, m->stream));
+    FCHK(hipStreamSynchronize(m->stream));
+#undef FCHK
+    cleanup();
     return ORB_OK;
 }
 

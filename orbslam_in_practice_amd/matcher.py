@@ -59,6 +59,21 @@ class ORBmatcher:
                                      self.mfNNratio, int(self.mbCheckOrientation), C.byref(nm)))
         return nm.value, m12
 
+    def GetFeaturesInArea(self, F, queries_xyr, levels=None, cap=None):
+        """Frame::GetFeaturesInArea (src/Frame.cpp:219-271, grid of :144-168) for every query row (x, y, r) on the
+        device (orb_features_in_area).  levels: (nq, 2) int32 (minLevel, maxLevel) or None = (-1, -1).
+        Returns (list of int32 index arrays in the reference's order, counts)."""
+        q = np.ascontiguousarray(queries_xyr, np.float32).reshape(-1, 3)
+        nq = len(q)
+        cap = int(cap if cap is not None else max(len(F.kps), 1))
+        lv = None if levels is None else np.ascontiguousarray(levels, np.int32).reshape(nq, 2)
+        out = np.full((max(nq, 1), cap), -1, np.int32)
+        cnt = np.zeros(max(nq, 1), np.int32)
+        v = F.view()
+        check(self._L.orb_features_in_area(self._m, C.byref(v), ptr(q) if nq else None, ptr(lv) if lv is not None else None,
+                                           nq, ptr(out), cap, ptr(cnt)))
+        return [out[i, :min(cnt[i], cap)].copy() for i in range(nq)], cnt[:nq]
+
     def DescriptorDistance(self, a, b):
         a = np.ascontiguousarray(a, np.uint8)
         b = np.ascontiguousarray(b, np.uint8)

@@ -106,3 +106,37 @@ def test_search_for_initialization_contention(oracle, n1, n2, nproto, flip, wind
         assert gn == on and np.array_equal(gm12, om12) and np.array_equal(prev, opm)
     assert on > 0 or nproto == 1  # (one prototype, 20 flips: every best/second pair fails the ratio test)
     m.close()
+
+
+def test_features_in_area_device(oracle, feats):
+    """the device GetFeaturesInArea (grid-free, rank-ordered) returns what the oracle's 64x48-cell
+    FrameGrid walk returns, index for index, for windows inside, across and outside the image and every level filter"""
+    import orbslam_in_practice_amd as oa
+    rng = np.random.default_rng(9)
+    b = (0.0, 640.0, 0.0, 480.0)
+    m = oa.ORBmatcher(0.9, True, max_keypoints=4096)
+    k2 = feats[1][0]
+    kp = np.concatenate([k2, k2[:50]])   # a few duplicates and out-of-bounds points
+    kp["x"][-50:-25] = rng.uniform(-30, 0, 25)
+    kp["y"][-25:] = rng.uniform(480, 520, 25)
+    F = oa.FrameFeatures(kp, np.zeros((len(kp), 32), np.uint8), b)
+    nq = 300
+    q = np.stack([rng.uniform(-60, 700, nq), rng.uniform(-60, 540, nq), rng.choice([0.5, 5, 30, 100, 400, 2000], nq)], 1)
+    q = q.astype(np.float32)
+    lv = np.stack([rng.integers(-1, 5, nq), rng.integers(-1, 8, nq)], 1).astype(np.int32)
+    for levels in (None, lv):
+        want, wc = oracle.features_in_area(kp, b, q, levels)
+        got, gc = m.GetFeaturesInArea(F, q, levels)
+        assert np.array_equal(gc, wc)
+        for a, c in zip(got, want):
+            assert np.array_equal(a, c)
+    assert wc.max() > 50 and (wc == 0).any()
+    # capacity smaller than the result: the first cap entries, full count reported
+    got, gc = m.GetFeaturesInArea(F, q[:20], None, cap=7)
+    want, wc = oracle.features_in_area(kp, b, q[:20], None, cap=7)
+    assert np.array_equal(gc, wc) and all(np.array_equal(a, c) for a, c in zip(got, want))
+    # empty frame / no queries
+    E = oa.FrameFeatures(np.zeros(0, oa.KP_DTYPE), np.zeros((0, 32), np.uint8), b)
+    got, gc = m.GetFeaturesInArea(E, q[:3])
+    assert all(len(a) == 0 for a in got) and np.all(gc == 0)
+    m.close()
