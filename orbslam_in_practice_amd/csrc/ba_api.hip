@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "../../include/orbslam_amd.h"
+#include "orb_common.h" /* PerDeviceLdsLimit */
 
 #define BA_T 512
 #define BA_W (BA_T / 64)
@@ -1444,12 +1445,10 @@ extern "C" int ba_solve_batch(BASolver *s, const BAProblem *probs, BAResult *res
         const int npmax = (maxn + 15) & ~15;
         const size_t need = (size_t)npmax * 17 + 2 * 16 * 17 + npmax;
         if (need * 8 <= 128 * 1024) dyn_doubles = (int)need; /* larger systems fall back to PCG inside the kernel */
-        static size_t attr_set = 0;
-        if ((size_t)dyn_doubles * 8 > attr_set) {
+        static PerDeviceLdsLimit lim;
+        if (lim.raise((size_t)dyn_doubles * 8))
             BCHK(hipFuncSetAttribute((const void *)k_ba_iteration, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      dyn_doubles * 8));
-            attr_set = (size_t)dyn_doubles * 8;
-        }
     }
     bool halted = false;
     for (int round = 0; round < P0.n_rounds && !halted; round++) {

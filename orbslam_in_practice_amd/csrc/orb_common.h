@@ -105,4 +105,20 @@ hipError_t orb_upload_constants();
 hipError_t launch_describe(const OrbGeom &g, const OrbBuffers &b, int n_frames, OrbKeyPoint *d_kps,
                            uint8_t *d_desc, int cap, int32_t *d_counts, hipStream_t st);
 
+
+/* hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember the largest size requested on each
+ * (a process normally owns one GPU; racing host threads at worst set the same attribute twice) */
+struct PerDeviceLdsLimit {
+    size_t set[64] = {};
+    bool raise(size_t bytes) {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
+        if (bytes > set[d]) {
+            set[d] = bytes;
+            return true;
+        }
+        return false;
+    }
+};
+
 #endif

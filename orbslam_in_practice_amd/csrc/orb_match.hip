@@ -767,11 +767,8 @@ static int launch_match(const MatchArgs &A_in, int n_pairs, hipStream_t st, hipE
         m_err = "matcher: keypoint capacity too large for the LDS-resident frame state";
         return ORB_E_CAPACITY;
     }
-    static size_t attr_set = 0;
-    if (lds > attr_set) {
-        MCHK(hipFuncSetAttribute((const void *)k_match_init, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = lds;
-    }
+    static PerDeviceLdsLimit lim;
+    if (lim.raise(lds)) MCHK(hipFuncSetAttribute((const void *)k_match_init, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (A.cap <= (A.window < 0 ? 65536 : 2048))
         hipLaunchKernelGGL(k_match_knn<true>, dim3((A.cap + 255) / 256, n_pairs), dim3(256), 0, st, A);
     else

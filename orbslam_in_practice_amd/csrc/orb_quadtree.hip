@@ -425,12 +425,11 @@ template <int NN> __global__ __launch_bounds__(NN / 2) void k_quadtree(OrbGeom g
 }
 
 template <int NN> static hipError_t launch_qt(const OrbGeom &g, const OrbBuffers &b, int n_frames, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceLdsLimit lim;
+    if (lim.raise(sizeof(QtShared<NN>))) {
         hipError_t e = hipFuncSetAttribute((const void *)k_quadtree<NN>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)sizeof(QtShared<NN>));
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     dim3 grid(g.nlevels, n_frames);
     hipLaunchKernelGGL(k_quadtree<NN>, grid, dim3(NN / 2), sizeof(QtShared<NN>), st, g, b.cells, (const uint32_t *)b.slab,
