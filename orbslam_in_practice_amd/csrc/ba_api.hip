@@ -1002,6 +1002,16 @@ __global__ __launch_bounds__(BA_T) void k_ba_classify(BABufs bufs, int drop_robu
 }
 
 /* ---------------------------------------------------------------------------------------------- */
+/* host staging of one window before concatenation; kept in the solver so that a steady stream of similar batches
+ * re-uses the vectors' capacity (allocating and freeing ~2 MB per window per call cost more than the staging) */
+struct BAPiece {
+    std::vector<double> D;
+    std::vector<int32_t> I;
+    std::vector<uint8_t> B;
+    size_t scratch = 0;
+    int rc = 0;
+};
+
 struct BASolver {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -1016,6 +1026,7 @@ struct BASolver {
     int32_t *pI = nullptr;
     uint8_t *pB = nullptr;
     size_t pcapD = 0, pcapI = 0, pcapB = 0;
+    std::vector<BAPiece> pieces;
     double pcg_tol2 = 1e-26; /* relative M^-1-norm of the residual, squared */
     int solver = 1;          /* 1 = dense blocked Cholesky (MFMA f64), 0 = PCG (ORBSLAM_AMD_BA_SOLVER=pcg) */
 };
@@ -1356,14 +1367,16 @@ extern "C" int ba_solve_batch(BASolver *s, const BAProblem *probs, BAResult *res
     {
         /* every window is staged into its own vectors on a pool of host threads (index sorting and the
            contribution lists are O(sum k^2) per window), then the pieces are concatenated */
-        struct Piece {
-            std::vector<double> D;
-            std::vector<int32_t> I;
-            std::vector<uint8_t> B;
-            size_t scratch = 0;
-            int rc = 0;
-        };
-        std::vector<Piece> pieces(nwin);
+        typedef BAPiece Piece;
+        if ((int)s->pieces.size() < nwin) s->pieces.resize(nwin);
+        std::vector<BAPiece> &pieces = s->pieces;
+        for (int i = 0; i < nwin; i++) {
+            pieces[i].D.clear();
+            pieces[i].I.clear();
+            pieces[i].B.clear();
+            pieces[i].scratch = 0;
+            pieces[i].rc = 0;
+        }
         const int nthr = std::max(1, std::min<int>(nwin, std::min<int>(16, (int)std::thread::hardware_concurrency())));
         auto work = [&](int t) {
             for (int i = t; i < nwin; i += nthr)
@@ -1479,24 +1492,42 @@ extern "C" int ba_solve_batch(BASolver *s, const BAProblem *probs, BAResult *res
     if (prof) BCHK(hipStreamSynchronize(s->stream));
     const double t_solved = tnow();
     /* results */
-    for (int i = 0; i < nwin; i++) { /* only poses, points and the LM state come back */
-        const BAWin &w = wins[i];
-        BCHK(hipMemcpyAsync(&s->pD[w.poses], s->dD + w.poses, (size_t)w.Nc * 7 * 8, hipMemcpyDeviceToHost, s->stream));
-        if (w.Np) BCHK(hipMemcpyAsync(&s->pD[w.pts], s->dD + w.pts, (size_t)w.Np * 3 * 8, hipMemcpyDeviceToHost, s->stream));
-        BCHK(hipMemcpyAsync(&s->pD[w.st], s->dD + w.st, (size_t)ST_COUNT * 8, hipMemcpyDeviceToHost, s->stream));
+    if (nwin >= 16) {
+        /* large batch: ONE copy of the whole staged region (observations included) beats three small copies per
+           window -- ~10 us of launch cost each against 57 GB/s of PCIe */
+        BCHK(hipMemcpyAsync(s->pD, s->dD, hD_n * 8, hipMemcpyDeviceToHost, s->stream));
+    } else {
+        for (int i = 0; i < nwin; i++) { /* only poses, points and the LM state come back */
+            const BAWin &w = wins[i];
+            BCHK(hipMemcpyAsync(&s->pD[w.poses], s->dD + w.poses, (size_t)w.Nc * 7 * 8, hipMemcpyDeviceToHost, s->stream));
+            if (w.Np) BCHK(hipMemcpyAsync(&s->pD[w.pts], s->dD + w.pts, (size_t)w.Np * 3 * 8, hipMemcpyDeviceToHost, s->stream));
+            BCHK(hipMemcpyAsync(&s->pD[w.st], s->dD + w.st, (size_t)ST_COUNT * 8, hipMemcpyDeviceToHost, s->stream));
+        }
     }
     if (hB_n) BCHK(hipMemcpyAsync(s->pB, s->dB, hB_n, hipMemcpyDeviceToHost, s->stream));
     BCHK(hipStreamSynchronize(s->stream));
-    for (int i = 0; i < nwin; i++) {
-        const BAWin &w = wins[i];
-        memcpy(res[i].poses, &s->pD[w.poses], (size_t)w.Nc * 7 * 8);
-        if (w.Np) memcpy(res[i].points, &s->pD[w.pts], (size_t)w.Np * 3 * 8);
-        if (res[i].outlier)
-            for (int k = 0; k < w.E; k++) res[i].outlier[hw[i].perm[k]] = (s->pB[w.flags + k] & 1) ? 0 : 1;
-        res[i].chi2_initial = s->pD[w.st + ST_CHI0];
-        res[i].chi2_final = s->pD[w.st + ST_CHI];
-        res[i].iterations = (int)s->pD[w.st + ST_ITERS];
-        res[i].lin_solves = (int)s->pD[w.st + ST_SOLVES];
+    {
+        auto unpack = [&](int t, int nt) {
+            for (int i = t; i < nwin; i += nt) {
+                const BAWin &w = wins[i];
+                memcpy(res[i].poses, &s->pD[w.poses], (size_t)w.Nc * 7 * 8);
+                if (w.Np) memcpy(res[i].points, &s->pD[w.pts], (size_t)w.Np * 3 * 8);
+                if (res[i].outlier)
+                    for (int k = 0; k < w.E; k++) res[i].outlier[hw[i].perm[k]] = (s->pB[w.flags + k] & 1) ? 0 : 1;
+                res[i].chi2_initial = s->pD[w.st + ST_CHI0];
+                res[i].chi2_final = s->pD[w.st + ST_CHI];
+                res[i].iterations = (int)s->pD[w.st + ST_ITERS];
+                res[i].lin_solves = (int)s->pD[w.st + ST_SOLVES];
+            }
+        };
+        const int nt = std::max(1, std::min<int>(nwin / 8, std::min<int>(16, (int)std::thread::hardware_concurrency())));
+        if (nt == 1)
+            unpack(0, 1);
+        else {
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nt; t++) pool.emplace_back(unpack, t, nt);
+            for (auto &th : pool) th.join();
+        }
     }
     if (prof) {
         double pcg = 0;
