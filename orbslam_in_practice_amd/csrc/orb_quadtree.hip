@@ -21,6 +21,8 @@
  * workgroup prefix scans in LDS.  No atomics, no host round trip, bit-exact list order.
  */
 #include "orb_common.h"
+#include <algorithm>
+#include <cstdlib>
 
 /* The node-list capacity NN is a template parameter (256 / 512 / 1024, picked from the largest per-level
  * quota); the workgroup has NN/2 threads so that the list-order scans handle two entries per thread. */
@@ -281,7 +283,7 @@ template <int NN> __device__ __forceinline__ int qt_pass(QtShared<NN> &s, int cu
 
 template <int NN> __global__ __launch_bounds__(NN / 2) void k_quadtree(OrbGeom g, const CellDesc *cells, const uint32_t *slab,
                                                     const int32_t *cell_cnt, uint32_t *keysA, uint32_t *keysB,
-                                                    int32_t *cand_cnt, uint32_t *lvl_kp, int32_t *lvl_cnt) {
+                                                    int32_t *cand_cnt, uint32_t *lvl_kp, int32_t *lvl_cnt, int lds_keys) {
     extern __shared__ __attribute__((aligned(16))) unsigned char qt_smem[];
     QtShared<NN> &s = *reinterpret_cast<QtShared<NN> *>(qt_smem);
     const int level = blockIdx.x, frame = blockIdx.y;
@@ -294,28 +296,68 @@ template <int NN> __global__ __launch_bounds__(NN / 2) void k_quadtree(OrbGeom g
     const int32_t *ccnt = cell_cnt + (int64_t)frame * g.total_cells + L.cell_base;
     const int ncell = L.n_cells;
 
-    /* ---- gather the per-cell FAST output into one array, cell-row-major (:777-783) ---- */
+    /* ---- where the keys live: LDS when the launch reserved room for them (few frames per call = latency mode:
+       every pass then costs LDS round trips instead of global ones) and this level's candidates fit, else the
+       global ping-pong arrays.  The pointers are generic, the passes do not care. ---- */
+    {
+        uint32_t mine = 0;
+        for (int c = tid; c < ncell; c += QT_T) mine += (uint32_t)ccnt[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+        if (lane == 0) s.wtot[wave] = mine;
+        __syncthreads();
+        uint32_t total = 0;
+        for (int w = 0; w < QT_W; w++) total += s.wtot[w];
+        __syncthreads();
+        if (lds_keys > 0 && total <= (uint32_t)lds_keys) {
+            k0 = reinterpret_cast<uint32_t *>(qt_smem + ((sizeof(QtShared<NN>) + 15) & ~(size_t)15));
+            k1 = k0 + lds_keys;
+        }
+    }
+    /* ---- gather the per-cell FAST output into one array, cell-row-major (:777-783): per chunk of QT_T cells an
+       exclusive scan of the cell counts, then a flat copy -- key j of the chunk finds its cell by binary search
+       over the scan, four independent loads in flight per thread ---- */
     uint32_t run = 0;
     for (int c0 = 0; c0 < ncell; c0 += QT_T) {
         const int c = c0 + tid;
         const uint32_t v = (c < ncell) ? (uint32_t)ccnt[c] : 0u;
+        const uint32_t soff = (c < ncell) ? (uint32_t)cells[L.cell_base + c].slab_off : 0u;
         uint32_t incl = wave_incl_scan(v, lane);
         if (lane == 63) s.wtot[wave] = incl;
         __syncthreads();
-        uint32_t base = run, tot = 0;
+        uint32_t base = 0, tot = 0;
         for (int w = 0; w < QT_W; w++) {
             if (w < wave) base += s.wtot[w];
             tot += s.wtot[w];
         }
-        if (c < ncell) s.scanL[tid] = base + incl - v; /* exclusive prefix of this chunk's cells */
-        if (c < ncell) s.scanR[tid] = v;
+        s.scanL[tid] = base + incl - v; /* exclusive prefix inside this chunk */
+        s.scanR[tid] = soff;
         __syncthreads();
         {
             const int nc = min(QT_T, ncell - c0);
-            for (int cc = wave; cc < nc; cc += QT_W) { /* one wavefront per cell: coalesced copy */
-                const uint32_t *src = fslab + cells[L.cell_base + c0 + cc].slab_off;
-                const uint32_t o = s.scanL[cc], vv = s.scanR[cc];
-                for (uint32_t k = lane; k < vv; k += 64) k0[o + k] = src[k];
+            for (uint32_t j0 = tid; j0 < tot; j0 += QT_T * 4) {
+                uint32_t val[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t j = j0 + u * QT_T;
+                    val[u] = 0;
+                    if (j < tot) {
+                        int lo = 0, hi = nc - 1; /* largest cell whose exclusive prefix is <= j */
+                        while (lo < hi) {
+                            const int mid = (lo + hi + 1) >> 1;
+                            if (s.scanL[mid] <= j)
+                                lo = mid;
+                            else
+                                hi = mid - 1;
+                        }
+                        val[u] = fslab[s.scanR[lo] + (j - s.scanL[lo])];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t j = j0 + u * QT_T;
+                    if (j < tot) k0[run + j] = val[u];
+                }
             }
         }
         run += tot;
@@ -425,21 +467,29 @@ template <int NN> __global__ __launch_bounds__(NN / 2) void k_quadtree(OrbGeom g
 }
 
 template <int NN> static hipError_t launch_qt(const OrbGeom &g, const OrbBuffers &b, int n_frames, hipStream_t st) {
-    static PerDeviceLdsLimit lim;
-    if (lim.raise(sizeof(QtShared<NN>))) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_quadtree<NN>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)sizeof(QtShared<NN>));
+    dim3 grid(g.nlevels, n_frames);
+    /* few frames per call = latency mode: reserve LDS for the key ping-pong of a level (a big batch keeps the keys
+       in global memory -- 2048 workgroups holding 100 KB of LDS each would starve the kernels running beside them) */
+    const size_t room = 128 * 1024 - ((sizeof(QtShared<NN>) + 15) & ~(size_t)15); /* keep the workgroup under 128 KB of LDS */
+    const int lds_keys = n_frames <= 8 ? (int)std::min<size_t>(12288, room / 8) : 0;
+    const size_t lds = ((sizeof(QtShared<NN>) + 15) & ~(size_t)15) + (size_t)lds_keys * 8;
+    static PerDeviceLdsLimit lim2;
+    if (lim2.raise(lds)) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_quadtree<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    dim3 grid(g.nlevels, n_frames);
-    hipLaunchKernelGGL(k_quadtree<NN>, grid, dim3(NN / 2), sizeof(QtShared<NN>), st, g, b.cells, (const uint32_t *)b.slab,
-                       (const int32_t *)b.cell_cnt, b.keysA, b.keysB, b.cand_cnt, b.lvl_kp, b.lvl_cnt);
+    hipLaunchKernelGGL(k_quadtree<NN>, grid, dim3(NN / 2), lds, st, g, b.cells, (const uint32_t *)b.slab,
+                       (const int32_t *)b.cell_cnt, b.keysA, b.keysB, b.cand_cnt, b.lvl_kp, b.lvl_cnt, lds_keys);
     return hipGetLastError();
 }
 
 hipError_t launch_quadtree(const OrbGeom &g, const OrbBuffers &b, int n_frames, hipStream_t st) {
     int need = 0;
     for (int l = 0; l < g.nlevels; l++) need = need > g.lv[l].out_cap ? need : g.lv[l].out_cap;
+    /* few frames per call (latency mode): the widest workgroup -- 8 wavefronts walk the nodes of a pass side by
+       side, 0.22 -> 0.11 ms for one 640x480 frame; a big batch has thousands of workgroups in flight and does
+       better with the narrow ones */
+    if (n_frames <= 8) return launch_qt<1024>(g, b, n_frames, st);
     if (need <= 256) return launch_qt<256>(g, b, n_frames, st);
     if (need <= 512) return launch_qt<512>(g, b, n_frames, st);
     return launch_qt<1024>(g, b, n_frames, st);
