@@ -43,6 +43,19 @@ def test_feature_counts_and_pyramid_shapes(oracle, nf, nlevels, scale):
     e.close()
 
 
+@pytest.mark.parametrize("scale,nlevels", [(2.0, 3), (3.0, 2), (4.5, 2)])
+def test_large_scale_steps(oracle, scale, nlevels):
+    """scale steps far beyond the reference's 1.2: the resize kernel's LDS window grows with the step and, past its
+    budget, the kernel falls back to direct gathers -- both must stay bit-exact"""
+    import orbslam_in_practice_amd as oa
+    from orbslam_in_practice_amd import synth
+    img = synth.make_frame(77, 1000, 760)
+    e = oa.ORBextractor(600, scale, nlevels, 20, 7, max_w=1000, max_h=760)
+    n = _same(e, oracle, img, 600, nlevels=nlevels, scale=scale)
+    assert n > 100
+    e.close()
+
+
 def test_noise_image_saturates_every_cell(oracle):
     import orbslam_in_practice_amd as oa
     rng = np.random.default_rng(11)
