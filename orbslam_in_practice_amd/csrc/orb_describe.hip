@@ -84,7 +84,9 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeom g, const uint8_t *pyr,
     const int item = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const int frame = item / (int)gridDim.x, bx = item - frame * (int)gridDim.x;
     const int lane = threadIdx.x & 63;
-    const int slot = bx * 4 + (threadIdx.x >> 6); /* slot in the frame's level-kp array */
+    /* wave-uniform by construction; readfirstlane tells the compiler, which then keeps the level search, the geometry
+       reads and every derived pointer on the scalar unit */
+    const int slot = bx * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); /* slot in the frame's level-kp array */
     const int32_t *lc = lvl_cnt + (int64_t)frame * g.nlevels;
     int level = 0, before = 0;
     while (level + 1 < g.nlevels && slot >= g.lv[level + 1].out_base) {
@@ -102,21 +104,26 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeom g, const uint8_t *pyr,
     if (idx >= lc[level]) return;
     const int oi = before + idx; /* position in the concatenated output (:1035-1063) */
     if (oi >= cap) return;
-    const uint32_t key = lvl_kp[(int64_t)frame * g.total_out_cap + slot];
+    /* the keypoint is the same for the whole wavefront: keep it (and every pointer derived from it) in SGPRs, so
+       that each patch / pattern read is "uniform base + 32-bit lane offset" instead of 64-bit pointer arithmetic
+       per lane and load */
+    const uint32_t key = (uint32_t)__builtin_amdgcn_readfirstlane((int)lvl_kp[(int64_t)frame * g.total_out_cap + slot]);
     const int px = KEY_X(key) + ORB_MIN_BORDER, py = KEY_Y(key) + ORB_MIN_BORDER; /* :799-800 */
+    const int pitch = L.pitch;
 
     /* ---- IC_Angle on the un-blurred level ---- */
     const uint8_t *img = level_ptr(pyr, g, frame, level);
-    const uint8_t *center = img + (int64_t)py * L.pitch + px;
+    const uint8_t *patch = img + (int64_t)(py - 15) * pitch + (px - 15); /* top-left of the 31 x 31 patch: offsets >= 0 */
     int m10 = 0, m01 = 0;
     {
         const int u = lane - 15;
         if (lane < 31) {
-            m10 = u * (int)center[u];
+            const uint32_t col = (uint32_t)lane; /* = u + 15 */
+            m10 = u * (int)patch[col + 15u * (uint32_t)pitch];
 #pragma unroll
             for (int v = 1; v <= 15; v++) {
                 if (u >= -c_umax[v] && u <= c_umax[v]) {
-                    int vp = center[u + v * L.pitch], vm = center[u - v * L.pitch];
+                    int vp = patch[col + (uint32_t)(15 + v) * (uint32_t)pitch], vm = patch[col + (uint32_t)(15 - v) * (uint32_t)pitch];
                     m01 += v * (vp - vm);
                     m10 += u * (vp + vm);
                 }
@@ -134,7 +141,8 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeom g, const uint8_t *pyr,
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     float a, b;
     sincos_det(angle * factorPI, &a, &b);
-    const uint8_t *bc = level_ptr(blur, g, frame, level) + (int64_t)py * L.pitch + px;
+    /* rotated pattern points stay within +-19 px of the keypoint (|p| <= 13 per axis, EDGE_THRESHOLD 19) */
+    const uint8_t *bc = level_ptr(blur, g, frame, level) + (int64_t)(py - 20) * pitch + (px - 20);
     uint64_t words[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeom g, const uint8_t *pyr,
         const float x0 = (float)p[0], y0 = (float)p[1], x1 = (float)p[2], y1 = (float)p[3];
         const int r0 = (int)rintf(x0 * b + y0 * a), q0 = (int)rintf(x0 * a - y0 * b);
         const int r1 = (int)rintf(x1 * b + y1 * a), q1 = (int)rintf(x1 * a - y1 * b);
-        const int t0 = bc[r0 * L.pitch + q0], t1 = bc[r1 * L.pitch + q1];
+        const int t0 = bc[(uint32_t)(__mul24(r0 + 20, pitch) + q0 + 20)], t1 = bc[(uint32_t)(__mul24(r1 + 20, pitch) + q1 + 20)];
         words[j] = __ballot(t0 < t1);
     }
     if (lane < 4) {
