@@ -207,7 +207,7 @@ struct BAShared {
 };
 
 __device__ __forceinline__ double block_sum(double v, BAShared &s) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); /* uniform: scalar unit */
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     __syncthreads();
@@ -218,7 +218,7 @@ __device__ __forceinline__ double block_sum(double v, BAShared &s) {
     return t;
 }
 __device__ __forceinline__ double block_max(double v, BAShared &s) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); /* uniform: scalar unit */
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
     __syncthreads();
@@ -275,7 +275,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 __device__ int g_chol_scalar = 0; /* debug: 1 = plain loops instead of MFMA */
 __device__ bool ba_chol_solve(const BAWin &w, double *D, const int32_t *I, int n, double *dyn, BAShared &s) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); /* uniform: scalar unit */
     const int np = (n + 15) & ~15, nb = np >> 4;
     double *A = D + w.A;
     double *Li = D + w.Linv;
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
     const int32_t *I = bufs.I;
     const uint8_t *B = bufs.B;
     double *st = D + w.st;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); /* uniform: scalar unit */
     if (st[ST_TERM] != 0.0) return; /* uniform: this window's round already terminated */
     const int n = w.Ncf * 6;
     /* profile mode: thread 0 accumulates wall time per phase (diagnostic build path only, never in timed runs) */
@@ -1561,7 +1561,7 @@ struct POShared {
 };
 
 __device__ __forceinline__ void po_reduce(double *v, int nv, POShared &s, double *out) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); /* uniform: scalar unit */
     for (int i = 0; i < nv; i++) {
         double t = v[i];
 #pragma unroll

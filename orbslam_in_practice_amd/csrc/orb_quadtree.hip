@@ -62,7 +62,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
 
 /* in-place inclusive scan of v[0..MAXN) (entries >= n must be 0); returns the total; all threads call */
 template <int NN> __device__ __forceinline__ uint32_t block_scan_incl(uint32_t *v, QtShared<NN> &s) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); /* uniform: scalar unit */
     uint32_t a = v[2 * tid], b = v[2 * tid + 1];
     uint32_t incl = wave_incl_scan(a + b, lane);
     if (lane == 63) s.wtot[wave] = incl;
@@ -87,7 +87,7 @@ __device__ __forceinline__ int quadrant(uint32_t key, int mx, int my) {
  * *n_to_expand the number of new children with >1 keys.  All threads call (uniform control flow). */
 template <int NN> __device__ __forceinline__ int qt_pass(QtShared<NN> &s, int cur, int nn, int N, int sorted, uint32_t *keys0, uint32_t *keys1,
                        int *n_to_expand) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); /* uniform: scalar unit */
     const int nxt = cur ^ 1;
     /* ---- A: candidates and their processing rank ---- */
     for (int e = 2 * tid; e < 2 * tid + 2; e++) {
@@ -288,7 +288,7 @@ template <int NN> __global__ __launch_bounds__(NN / 2) void k_quadtree(OrbGeom g
     QtShared<NN> &s = *reinterpret_cast<QtShared<NN> *>(qt_smem);
     const int level = blockIdx.x, frame = blockIdx.y;
     const LevelGeom &L = g.lv[level];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); /* uniform: scalar unit */
     const int N = L.quota;
     uint32_t *k0 = keysA + (int64_t)frame * g.key_frame_count + L.key_off;
     uint32_t *k1 = keysB + (int64_t)frame * g.key_frame_count + L.key_off;
