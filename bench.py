@@ -106,7 +106,15 @@ def ba_throughput(device, n_windows):
         res = opt.solve_batch(wins, (5, 10))
     dt = (time.perf_counter() - t0) / reps
     opt.close()
+    # the CPU oracle (dense Cholesky on the Schur complement, g2o semantics) on a bounded sample of the same windows
+    from oracle import oracle as orc
+    t1 = time.perf_counter()
+    for w in uniq:
+        orc.ba_solve(w, rounds=(5, 10))
+    cpu_dt = (time.perf_counter() - t1) / len(uniq)
     return {"value": round(n_windows / dt, 2), "unit": "windows/s", "dtype": "f64",
+            "cpu_baseline": {"value": round(1.0 / cpu_dt, 3), "unit": "windows/s", "cores": 1, "kind": "port",
+                             "sample": "%d of the same windows through oracle/ba_oracle.cpp, %.1f s" % (len(uniq), cpu_dt * len(uniq))},
             "workload": "local BA, %d windows of 100 KFs x 5000 points (E~%d), 5+10 LM iterations, host staging "
                         "included, mean of %d calls" % (n_windows, E, reps),
             "chi2_ratio": round(float(np.mean([r["chi2_final"] / r["chi2_initial"] for r in res])), 5)}
@@ -119,7 +127,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=512, help="frames per GPU per step")
-    ap.add_argument("--cpu-frames", type=int, default=48, help="CPU baseline sample size (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=200, help="CPU baseline sample size (0 = skip); 200 frames = ~9 s on one core")
     ap.add_argument("--size", default="640x480", help="frame size WxH (configs[1] = 640x480; 1280x720 = configs[3] shape)")
     ap.add_argument("--window", type=int, default=-1, help="match window (-1 = brute force; 100 = the reference's "
                     "SearchForInitialization call, src/Tracking.cpp:189)")
