@@ -13,13 +13,16 @@
  *     its edges are contiguous), W = Hpl blocks (6x3 per edge), Hpp (6x6, one wavefront per camera with
  *     shuffle reductions) -> LM trials: Dinv = (Hll + lambda I)^-1, Y = W Dinv, block-sparse reduced
  *     camera system S = Hpp + lambda I - sum Y W^T (one wavefront per non-zero 6x6 block, fixed
- *     contribution order: no atomics, bit-reproducible), g = bp - sum Y bl -> PCG with block-Jacobi
- *     preconditioner (p, r in LDS, row-per-thread block-CSR product) -> back-substitution -> exp-map
- *     update -> trial chi2 -> gain ratio / lambda update exactly as OptimizationAlgorithmLevenberg.
+ *     contribution order: no atomics, bit-reproducible), g = bp - sum Y bl -> dense blocked Cholesky of S
+ *     inside its envelope (ba_chol_solve: 16 x 16 tiles, panel solve and trailing update on
+ *     v_mfma_f64_16x16x4_f64) -- or PCG with block-Jacobi preconditioner (p, r in LDS, row-per-thread
+ *     block-CSR product) when the LDS panel does not fit or ORBSLAM_AMD_BA_SOLVER=pcg asks for it ->
+ *     back-substitution -> exp-map update -> trial chi2 -> gain ratio / lambda update exactly as
+ *     OptimizationAlgorithmLevenberg.
  *
- * MFMA note: on gfx950 the f64 matrix rate equals the f64 vector rate (78.6 TFLOP/s both) and the
- * reduced system product is a matrix-VECTOR product served from L2, so v_mfma_f64 buys nothing here;
- * the S p product stays on the vector ALU (BA section).
+ * MFMA note: on gfx950 the f64 matrix rate equals the f64 vector rate (78.6 TFLOP/s both); the matrix cores
+ * are used where the work is GEMM-shaped (the Cholesky panel/trailing products: 64 FMAs per issued
+ * instruction), not for the matrix-vector products of PCG, which stream S from L2.
  *
  * No CPU fallback: the host code below only sorts indices and moves buffers.
  */
