@@ -230,7 +230,7 @@ __device__ __forceinline__ int fast_score16_ld(const uint8_t *c, int v, int ld) 
  * brighter, or all darker" is then a bitwise AND over nine consecutive X words read off the two sign bits:
  * 16 three-input ANDs give the runs of 3, 16 more the runs of 9 (gfx950 v_bitop3_b32), an OR tree merges the 16
  * arcs.  Under half the instructions of the exact score, which only the few percent of pixels that pass need. */
-__device__ __forceinline__ bool fast_is_corner_ld(const uint8_t *c, int ld, uint32_t tt) {
+__device__ __forceinline__ int fast_is_corner_ld(const uint8_t *c, int ld, uint32_t tt) {
     /* row pointers from the top-left corner of the 7x7 window: every LDS offset is a non-negative immediate */
     const uint8_t *q0 = c - 3 * ld - 3, *q1 = q0 + ld, *q2 = q0 + 2 * ld, *q3 = q0 + 3 * ld, *q4 = q0 + 4 * ld, *q5 = q0 + 5 * ld,
                   *q6 = q0 + 6 * ld;
@@ -262,7 +262,67 @@ __device__ __forceinline__ bool fast_is_corner_ld(const uint8_t *c, int ld, uint
     for (int k = 0; k < 16; k++) t9[k] = t3[k] & t3[(k + 3) & 15] & t3[(k + 6) & 15];
     const uint32_t o0 = t9[0] | t9[1] | t9[2], o1 = t9[3] | t9[4] | t9[5], o2 = t9[6] | t9[7] | t9[8], o3 = t9[9] | t9[10] | t9[11],
                    o4 = t9[12] | t9[13] | t9[14];
-    return (((o0 | o1 | o2) | (o3 | o4 | t9[15])) & 0x80008000u) != 0;
+    /* a bright and a dark 9-arc cannot coexist on a 16-ring (they would share two pixels): at most one bit is set */
+    const uint32_t o = ((o0 | o1 | o2) | (o3 | o4 | t9[15])) & 0x80008000u;
+    return o == 0 ? 0 : ((o & 0x8000u) ? 1 : 2); /* 1: brighter arc, 2: darker arc */
+}
+
+/* Exact cornerScore of TWO corners of known polarity in one pass.  For polarity s (+1 bright, -1 dark) the score is
+ * max over the 16 nine-arcs of min_k s*(r[k] - v), minus 1 -- the other polarity cannot win (see above).  The two
+ * pixels ride in the halves of one register as biased non-negative values d = s*(r - v) + 256 (0..511), built
+ * with two v_mad_i32_i24 per ring position (the second shifts its product into the high half), and share ONE
+ * sliding-minimum network of v_pk_min_i16 / v_pk_max_i16. */
+__device__ __forceinline__ uint32_t fast_score_pair_ld(const uint8_t *ca, int sa, const uint8_t *cb, int sb, int ld) {
+    const uint8_t *a0 = ca - 3 * ld - 3, *a1 = a0 + ld, *a2 = a0 + 2 * ld, *a3 = a0 + 3 * ld, *a4 = a0 + 4 * ld, *a5 = a0 + 5 * ld,
+                  *a6 = a0 + 6 * ld;
+    const uint8_t *b0 = cb - 3 * ld - 3, *b1 = b0 + ld, *b2 = b0 + 2 * ld, *b3 = b0 + 3 * ld, *b4 = b0 + 4 * ld, *b5 = b0 + 5 * ld,
+                  *b6 = b0 + 6 * ld;
+    int ra[16], rb[16];
+    ra[0] = a6[3];  rb[0] = b6[3];
+    ra[1] = a6[4];  rb[1] = b6[4];
+    ra[2] = a5[5];  rb[2] = b5[5];
+    ra[3] = a4[6];  rb[3] = b4[6];
+    ra[4] = a3[6];  rb[4] = b3[6];
+    ra[5] = a2[6];  rb[5] = b2[6];
+    ra[6] = a1[5];  rb[6] = b1[5];
+    ra[7] = a0[4];  rb[7] = b0[4];
+    ra[8] = a0[3];  rb[8] = b0[3];
+    ra[9] = a0[2];  rb[9] = b0[2];
+    ra[10] = a1[1]; rb[10] = b1[1];
+    ra[11] = a2[0]; rb[11] = b2[0];
+    ra[12] = a3[0]; rb[12] = b3[0];
+    ra[13] = a4[0]; rb[13] = b4[0];
+    ra[14] = a5[1]; rb[14] = b5[1];
+    ra[15] = a6[2]; rb[15] = b6[2];
+    const int va = a3[3], vb = b3[3];
+    /* K = (256 - sa*va) + ((256 - sb*vb) << 16); word[k] = K + sa*ra[k] + (sb*rb[k] << 16): both halves in 0..511 */
+    int K = (256 - sa * va) + ((256 - sb * vb) << 16);
+    asm volatile("" : "+v"(K)); /* opaque: keeps each word two plain mads */
+    const int sb16 = sb * 65536;
+    v2s p[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int w = __mul24(rb[k], sb16) + (__mul24(ra[k], sa) + K);
+        p[k] = __builtin_bit_cast(v2s, w);
+    }
+    v2s w2[16], w4[16], w8[16], w9[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) w2[k] = __builtin_elementwise_min(p[k], p[(k + 1) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) w4[k] = __builtin_elementwise_min(w2[k], w2[(k + 2) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) w8[k] = __builtin_elementwise_min(w4[k], w4[(k + 4) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) w9[k] = __builtin_elementwise_min(w8[k], p[(k + 8) & 15]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) w9[k] = __builtin_elementwise_max(w9[k], w9[k + 8]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) w9[k] = __builtin_elementwise_max(w9[k], w9[k + 4]);
+#pragma unroll
+    for (int k = 0; k < 2; k++) w9[k] = __builtin_elementwise_max(w9[k], w9[k + 2]);
+    const v2s best = __builtin_elementwise_max(w9[0], w9[1]);
+    const uint32_t sc_a = (uint32_t)((int)best.x - 257), sc_b = (uint32_t)((int)best.y - 257);
+    return sc_a | (sc_b << 16);
 }
 
 /* ONE WAVEFRONT per (cell, frame): a 64-thread workgroup, LDS tiles sized to the largest cell of the current
@@ -270,7 +330,7 @@ __device__ __forceinline__ bool fast_is_corner_ld(const uint8_t *c, int ld, uint
  *   pass A0 compass pre-test (4 ring pixels) of the detection zone in dense 64-pixel row-major chunks; survivors
  *           (about a quarter) are appended, in order, to an LDS queue by ballot/popcount prefix;
  *   pass A  full corner test at minThFAST of the queued pixels, queue compacted in place (about a tenth remain);
- *   pass S  exact cornerScore of the queued pixels only, 64 per step;
+ *   pass S  exact cornerScore of the queued pixels only, two per lane (one shared network), 128 per step;
  *   pass B  3x3 non-maximum suppression of the queued pixels, flags kept / kept-and->=iniThFAST written back
  *           into the queue entry;
  *   pass C  ordered emission of the queue entries selected by the per-cell threshold fallback. */
@@ -333,26 +393,30 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(OrbGeom g, const uint8_t
 #pragma unroll 1
     for (int j0 = 0; j0 < nq0; j0 += 64) {
         const int j = j0 + lane;
-        bool hit = false;
-        int e = 0;
+        int pol = 0, e = 0;
         if (j < nq0) {
             e = s_q[j];
-            hit = fast_is_corner_ld(s_px + __mul24(e >> 7, ld) + (e & 127), ld, tt);
+            pol = fast_is_corner_ld(s_px + __mul24(e >> 7, ld) + (e & 127), ld, tt);
         }
         __syncthreads();
+        const bool hit = pol != 0;
         const uint64_t m = __ballot(hit);
-        if (hit) s_q[nq + __popcll(m & lt)] = (uint16_t)e;
+        if (hit) s_q[nq + __popcll(m & lt)] = (uint16_t)(e | (pol == 2 ? 1 << 14 : 0)); /* bit 14: darker arc */
         nq += __popcll(m);
     }
     __syncthreads();
-    /* pass S */
+    /* pass S: two queued corners per lane (entries j and j + 64 of each 128-entry step) */
 #pragma unroll 1
-    for (int j0 = 0; j0 < nq; j0 += 64) {
-        const int j = j0 + lane;
-        if (j < nq) {
-            const int e = s_q[j];
-            const int pos = __mul24(e >> 7, ld) + (e & 127);
-            s_sc[pos] = (uint8_t)fast_score16_ld(s_px + pos, (int)s_px[pos], ld);
+    for (int j0 = 0; j0 < nq; j0 += 128) {
+        const int ja = j0 + lane, jb = ja + 64;
+        if (ja < nq) {
+            const int ea = s_q[ja], eb = jb < nq ? (int)s_q[jb] : ea;
+            const int pa = __mul24((ea >> 7) & 127, ld) + (ea & 127), pb = __mul24((eb >> 7) & 127, ld) + (eb & 127);
+            const uint32_t sc = fast_score_pair_ld(s_px + pa, (ea & (1 << 14)) ? -1 : 1, s_px + pb, (eb & (1 << 14)) ? -1 : 1, ld);
+            s_sc[pa] = (uint8_t)(sc & 0xFFFFu);
+            if (jb < nq) s_sc[pb] = (uint8_t)(sc >> 16);
+            s_q[ja] = (uint16_t)(ea & 0x3FFF); /* the polarity bit has served: bits 14/15 become the NMS flags */
+            if (jb < nq) s_q[jb] = (uint16_t)(eb & 0x3FFF);
         }
     }
     __syncthreads();
