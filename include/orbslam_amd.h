@@ -149,7 +149,8 @@ int orb_match_init(OrbMatcher *m, const OrbFrameView *f1, const OrbFrameView *f2
  * for a batch of queries against one frame's keypoints, on the device: queries_xyr[3*q] = (x, y, r),
  * query_levels[2*q] = (minLevel, maxLevel) or NULL for (-1, -1) (no level filter, as :245 computes it).
  * out_idx[q*cap + k] receives the indices the reference returns, in its order (grid cell column-major, then
- * insertion order), -1 padded; out_count[q] the full count (entries beyond cap are dropped).  Host pointers. */
+ * insertion order), -1 padded; out_count[q] the full count (entries beyond cap are dropped).  Host pointers;
+ * frames of up to 16384 keypoints (ORB_E_CAPACITY beyond). */
 int orb_features_in_area(OrbMatcher *m, const OrbFrameView *f, const float *queries_xyr, const int32_t *query_levels,
                          int n_queries, int32_t *out_idx, int cap, int32_t *out_count);
 

@@ -44,7 +44,7 @@
 #define BA_W (BA_T / 64)
 #define BA_MAX_N 1536 /* reduced system size (6 * free cameras) that fits the LDS vectors */
 
-static thread_local std::string b_err;
+static OrbErrSlot b_err; /* forwards to orb_last_error() */
 #define BCHK(expr)                                                          \
     do {                                                                    \
         hipError_t _e = (expr);                                             \

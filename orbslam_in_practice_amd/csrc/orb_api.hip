@@ -34,6 +34,7 @@ static void set_err(const char *what, hipError_t e, const char *file, int line) 
     } while (0)
 
 extern "C" const char *orb_last_error(void) { return g_err.c_str(); }
+void orb_set_last_error(const char *msg) { g_err = msg ? msg : ""; }
 
 extern "C" int orb_device_count(void) {
     int n = 0;

@@ -3,6 +3,7 @@
 #define ORB_COMMON_H
 
 #include <hip/hip_runtime.h>
+#include <string>
 #include <stdint.h>
 
 #include "../../include/orbslam_amd.h"
@@ -118,6 +119,21 @@ struct PerDeviceLdsLimit {
             return true;
         }
         return false;
+    }
+};
+
+
+/* one error text per host thread for the whole library (orb_last_error()): the matcher and BA translation units
+ * forward theirs through this slot */
+void orb_set_last_error(const char *msg);
+struct OrbErrSlot {
+    OrbErrSlot &operator=(const std::string &s) {
+        orb_set_last_error(s.c_str());
+        return *this;
+    }
+    OrbErrSlot &operator=(const char *s) {
+        orb_set_last_error(s);
+        return *this;
     }
 };
 

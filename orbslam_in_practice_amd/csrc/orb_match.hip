@@ -564,7 +564,7 @@ __global__ __launch_bounds__(64) void k_features_in_area(const OrbKeyPoint *kps,
 }
 
 /* ------------------------------------------------------------------------------------------------ */
-static thread_local std::string m_err;
+static OrbErrSlot m_err; /* forwards to orb_last_error() */
 #define MCHK(expr)                                                                         \
     do {                                                                                   \
         hipError_t _e = (expr);                                                            \
@@ -836,7 +836,10 @@ extern "C" int orb_features_in_area(OrbMatcher *m, const OrbFrameView *f, const 
     if (!m || !f || f->n < 0 || n_queries < 0 || cap < 0 || (n_queries > 0 && (!queries_xyr || !out_count)) ||
         (n_queries > 0 && cap > 0 && !out_idx) || (f->n > 0 && !f->kps))
         return ORB_E_INVALID;
-    if (f->n > m->max_kp || f->n > 65535) return ORB_E_CAPACITY;
+    if (f->n > m->max_kp || f->n > 16384) { /* the candidate keys of one query live in (static-limit) LDS: 4 B per keypoint */
+        m_err = "orb_features_in_area: more than 16384 keypoints (or than the matcher's capacity) in the frame";
+        return ORB_E_CAPACITY;
+    }
     if (n_queries == 0) return ORB_OK;
     MCHK(hipSetDevice(m->device));
     float *d_q = nullptr;

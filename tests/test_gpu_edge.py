@@ -124,3 +124,30 @@ def test_matcher_edge_cases(oracle):
     on, om12, _ = oracle.search_for_initialization(kp2, d, kp2, d, b, prev2.copy(), 50, 0.9, True)
     assert n == on and np.array_equal(m12, om12)
     m.close()
+
+
+def test_error_text_of_matcher_and_ba_reaches_orb_last_error():
+    """one error slot per host thread for the whole library: a BA / matcher failure's text is what
+    orb_last_error() (and hence OrbError) reports, not a stale extractor message"""
+    import orbslam_in_practice_amd as oa
+    from orbslam_in_practice_amd import synth
+    o = oa.Optimizer(max_cams=16, max_points=256, max_obs=4096, max_batch=2)
+    w1, w2 = synth.make_ba_window(1, 6, 100), synth.make_ba_window(2, 6, 100)
+    Ps = (oa._lib.BAProblem * 2)()
+    Rs = (oa._lib.BAResult * 2)()
+    k1 = oa.Optimizer._fill(Ps[0], w1, (5, 10), True, 5.991, 0, None)
+    k2 = oa.Optimizer._fill(Ps[1], w2, (3,), True, 5.991, 0, None)   # a different schedule in one batch
+    bufs = [np.zeros((6, 7)), np.zeros((100, 3)), np.zeros((6, 7)), np.zeros((100, 3))]
+    Rs[0].poses, Rs[0].points, Rs[1].poses, Rs[1].points = [b.ctypes.data for b in bufs]
+    with pytest.raises(oa.OrbError) as ei:
+        oa._lib.check(o._L.ba_solve_batch(o._s, Ps, Rs, 2))
+    assert ei.value.code == oa._lib.ORB_E_INVALID and "one iteration schedule" in str(ei.value)
+    o.close()
+    m = oa.ORBmatcher(0.9, True, max_keypoints=32768)
+    kp = np.zeros(20000, oa.KP_DTYPE)
+    F = oa.FrameFeatures(kp, np.zeros((20000, 32), np.uint8), (0.0, 640.0, 0.0, 480.0))
+    with pytest.raises(oa.OrbError) as ei:
+        m.GetFeaturesInArea(F, np.array([[10.0, 10.0, 5.0]], np.float32))
+    assert ei.value.code == oa._lib.ORB_E_CAPACITY and "16384" in str(ei.value)
+    m.close()
+    del k1, k2
