@@ -583,6 +583,10 @@ struct OrbMatcher {
     uint8_t *d_desc = nullptr;    /* [2][max_kp][32] */
     int32_t *d_counts = nullptr;  /* [2] */
     float *d_prev = nullptr, *d_prev_out = nullptr; /* [max_kp][2] */
+    uint8_t *d_in = nullptr;  /* one device block behind d_counts / d_kps / d_desc / d_prev: the host-pointer path uploads it in one copy */
+    uint8_t *h_up = nullptr;  /* pinned mirror of d_in */
+    uint8_t *h_down = nullptr; /* pinned results of the host-pointer path: [nmatches 64 B | matches12 K*4 | prev_out K*8] */
+    size_t in_bytes = 0, off_kps = 0, off_desc = 0, off_prev = 0;
     int32_t *d_m12 = nullptr;     /* [max_pairs][max_kp] */
     int32_t *d_nm = nullptr;      /* [max_pairs] */
     uint8_t *d_bins = nullptr;    /* [max_pairs][max_kp] */
@@ -605,10 +609,15 @@ extern "C" int orb_matcher_create(int max_keypoints, int max_pairs, int device_i
     m->max_kp = max_keypoints;
     m->max_pairs = max_pairs;
     const size_t K = (size_t)max_keypoints;
+    /* input block: [counts 64 B | kps 2K x 28 | desc 2K x 32 | prev K x 8], every part 64-B aligned */
+    auto al64 = [](size_t v) { return (v + 63) & ~(size_t)63; };
+    m->off_kps = 64;
+    m->off_desc = al64(m->off_kps + 2 * K * sizeof(OrbKeyPoint));
+    m->off_prev = al64(m->off_desc + 2 * K * 32);
+    m->in_bytes = al64(m->off_prev + K * 8);
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc((void **)&m->d_kps, 2 * K * sizeof(OrbKeyPoint)) != hipSuccess ||
-        hipMalloc((void **)&m->d_desc, 2 * K * 32) != hipSuccess || hipMalloc((void **)&m->d_counts, 16) != hipSuccess ||
-        hipMalloc((void **)&m->d_prev, K * 8) != hipSuccess || hipMalloc((void **)&m->d_prev_out, K * 8) != hipSuccess ||
+        hipMalloc((void **)&m->d_in, m->in_bytes) != hipSuccess || hipHostMalloc((void **)&m->h_up, m->in_bytes) != hipSuccess ||
+        hipHostMalloc((void **)&m->h_down, 64 + K * 12) != hipSuccess || hipMalloc((void **)&m->d_prev_out, K * 8) != hipSuccess ||
         hipMalloc((void **)&m->d_m12, (size_t)max_pairs * K * 4) != hipSuccess ||
         hipMalloc((void **)&m->d_nm, (size_t)max_pairs * 4) != hipSuccess ||
         hipMalloc((void **)&m->d_bins, (size_t)max_pairs * K) != hipSuccess ||
@@ -618,6 +627,10 @@ extern "C" int orb_matcher_create(int max_keypoints, int max_pairs, int device_i
         orb_matcher_destroy(m);
         return ORB_E_HIP;
     }
+    m->d_counts = (int32_t *)m->d_in;
+    m->d_kps = (OrbKeyPoint *)(m->d_in + m->off_kps);
+    m->d_desc = m->d_in + m->off_desc;
+    m->d_prev = (float *)(m->d_in + m->off_prev);
     *out = m;
     return ORB_OK;
 }
@@ -626,10 +639,9 @@ extern "C" void orb_matcher_destroy(OrbMatcher *m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
-    (void)hipFree(m->d_kps);
-    (void)hipFree(m->d_desc);
-    (void)hipFree(m->d_counts);
-    (void)hipFree(m->d_prev);
+    (void)hipFree(m->d_in); /* d_counts / d_kps / d_desc / d_prev live inside it */
+    if (m->h_up) (void)hipHostFree(m->h_up);
+    if (m->h_down) (void)hipHostFree(m->h_down);
     (void)hipFree(m->d_prev_out);
     (void)hipFree(m->d_m12);
     (void)hipFree(m->d_nm);
@@ -792,15 +804,30 @@ extern "C" int orb_match_init(OrbMatcher *m, const OrbFrameView *f1, const OrbFr
     MCHK(hipSetDevice(m->device));
     const size_t K = (size_t)m->max_kp;
     int32_t counts[2] = {f1->n, f2->n};
-    MCHK(hipMemcpyAsync(m->d_counts, counts, 8, hipMemcpyHostToDevice, m->stream));
-    MCHK(hipMemcpyAsync(m->d_kps, f1->kps, (size_t)f1->n * sizeof(OrbKeyPoint), hipMemcpyHostToDevice, m->stream));
-    MCHK(hipMemcpyAsync(m->d_desc, f1->desc, (size_t)f1->n * 32, hipMemcpyHostToDevice, m->stream));
+    /* stage the two frames in the pinned mirror of the device input block; a small block goes up in ONE copy
+       (pageable sources would cost a blocking bounce per copy), a large one part by part */
+    memcpy(m->h_up, counts, 8);
+    memcpy(m->h_up + m->off_kps, f1->kps, (size_t)f1->n * sizeof(OrbKeyPoint));
+    memcpy(m->h_up + m->off_desc, f1->desc, (size_t)f1->n * 32);
     if (f2->n > 0) {
-        MCHK(hipMemcpyAsync(m->d_kps + K, f2->kps, (size_t)f2->n * sizeof(OrbKeyPoint), hipMemcpyHostToDevice, m->stream));
-        MCHK(hipMemcpyAsync(m->d_desc + K * 32, f2->desc, (size_t)f2->n * 32, hipMemcpyHostToDevice, m->stream));
+        memcpy(m->h_up + m->off_kps + K * sizeof(OrbKeyPoint), f2->kps, (size_t)f2->n * sizeof(OrbKeyPoint));
+        memcpy(m->h_up + m->off_desc + K * 32, f2->desc, (size_t)f2->n * 32);
     }
-    if (prev_matched_xy)
-        MCHK(hipMemcpyAsync(m->d_prev, prev_matched_xy, (size_t)f1->n * 8, hipMemcpyHostToDevice, m->stream));
+    if (prev_matched_xy) memcpy(m->h_up + m->off_prev, prev_matched_xy, (size_t)f1->n * 8);
+    if (m->in_bytes <= (size_t)1 << 20) {
+        MCHK(hipMemcpyAsync(m->d_in, m->h_up, m->in_bytes, hipMemcpyHostToDevice, m->stream));
+    } else {
+        MCHK(hipMemcpyAsync(m->d_in, m->h_up, 64, hipMemcpyHostToDevice, m->stream));
+        MCHK(hipMemcpyAsync(m->d_kps, m->h_up + m->off_kps, (size_t)f1->n * sizeof(OrbKeyPoint), hipMemcpyHostToDevice, m->stream));
+        MCHK(hipMemcpyAsync(m->d_desc, m->h_up + m->off_desc, (size_t)f1->n * 32, hipMemcpyHostToDevice, m->stream));
+        if (f2->n > 0) {
+            MCHK(hipMemcpyAsync(m->d_kps + K, m->h_up + m->off_kps + K * sizeof(OrbKeyPoint), (size_t)f2->n * sizeof(OrbKeyPoint),
+                                hipMemcpyHostToDevice, m->stream));
+            MCHK(hipMemcpyAsync(m->d_desc + K * 32, m->h_up + m->off_desc + K * 32, (size_t)f2->n * 32, hipMemcpyHostToDevice, m->stream));
+        }
+        if (prev_matched_xy)
+            MCHK(hipMemcpyAsync(m->d_prev, m->h_up + m->off_prev, (size_t)f1->n * 8, hipMemcpyHostToDevice, m->stream));
+    }
     MatchArgs A{};
     A.kps = m->d_kps;
     A.desc = m->d_desc;
@@ -823,11 +850,14 @@ extern "C" int orb_match_init(OrbMatcher *m, const OrbFrameView *f1, const OrbFr
     A.knn = m->d_knn;
     int rc = launch_match(A, 1, m->stream);
     if (rc) return rc;
-    MCHK(hipMemcpyAsync(matches12, m->d_m12, (size_t)f1->n * 4, hipMemcpyDeviceToHost, m->stream));
-    MCHK(hipMemcpyAsync(n_matches, m->d_nm, 4, hipMemcpyDeviceToHost, m->stream));
+    MCHK(hipMemcpyAsync(m->h_down + 64, m->d_m12, (size_t)f1->n * 4, hipMemcpyDeviceToHost, m->stream));
+    MCHK(hipMemcpyAsync(m->h_down, m->d_nm, 4, hipMemcpyDeviceToHost, m->stream));
     if (prev_matched_xy)
-        MCHK(hipMemcpyAsync(prev_matched_xy, m->d_prev_out, (size_t)f1->n * 8, hipMemcpyDeviceToHost, m->stream));
+        MCHK(hipMemcpyAsync(m->h_down + 64 + K * 4, m->d_prev_out, (size_t)f1->n * 8, hipMemcpyDeviceToHost, m->stream));
     MCHK(hipStreamSynchronize(m->stream));
+    memcpy(matches12, m->h_down + 64, (size_t)f1->n * 4);
+    memcpy(n_matches, m->h_down, 4);
+    if (prev_matched_xy) memcpy(prev_matched_xy, m->h_down + 64 + K * 4, (size_t)f1->n * 8);
     return ORB_OK;
 }
 
