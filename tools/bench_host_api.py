@@ -39,3 +39,15 @@ for _ in range(20):
 mlat = (time.perf_counter() - t0) / 20
 print(json.dumps({"orb_extract_single_frame_ms": round(lat * 1e3, 3), "orb_extract_single_fps": round(1 / lat, 1),
                   "orb_extract_batch64_host_fps": round(thr, 1), "orb_match_init_window100_ms": round(mlat * 1e3, 3)}))
+
+# pose-only optimisation the way Tracking calls it (one frame, a few hundred map-point correspondences)
+w = synth.make_ba_window(11, 6, 1000, outlier_frac=0.1)
+sel = w["cam_idx"] == 3
+xw, obs, info, pose0 = w["gt_points"][w["pt_idx"][sel]], w["obs"][sel], w["inv_sigma2"][sel], w["poses"][3]
+opt = oa.Optimizer(max_cams=8, max_points=8, max_obs=8, max_batch=1)
+opt.PoseOptimization(pose0, xw, obs, info, w["fx"], w["fy"], w["cx"], w["cy"])
+t0 = time.perf_counter()
+for _ in range(20):
+    opt.PoseOptimization(pose0, xw, obs, info, w["fx"], w["fy"], w["cx"], w["cy"])
+plat = (time.perf_counter() - t0) / 20
+print(json.dumps({"pose_optimization_ms": round(plat * 1e3, 3), "correspondences": int(sel.sum())}))
