@@ -107,18 +107,28 @@ __device__ __forceinline__ void R_to_quat(const double R[9], double q[4]) {
         q[2] = (R[2] - R[6]) * t;
         q[3] = (R[3] - R[1]) * t;
     } else {
+        /* Eigen's branch on the largest diagonal entry, written out for the three cases so that every index is a
+           constant and R[] stays in registers (run-time indices put it in scratch memory) */
         int i = 0;
         if (R[4] > R[0]) i = 1;
-        if (R[8] > R[i * 4]) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrt(R[i * 4] - R[j * 4] - R[k * 4] + 1.0);
-        double v[3];
-        v[i] = 0.5 * t;
-        t = 0.5 / t;
-        q[0] = (R[k * 3 + j] - R[j * 3 + k]) * t;
-        v[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
-        v[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
-        q[1] = v[0]; q[2] = v[1]; q[3] = v[2];
+        if (R[8] > (i == 0 ? R[0] : R[4])) i = 2;
+#define R2Q_CASE(I, J, K)                                        \
+    {                                                            \
+        t = sqrt(R[I * 4] - R[J * 4] - R[K * 4] + 1.0);          \
+        const double vi = 0.5 * t;                               \
+        t = 0.5 / t;                                             \
+        q[0] = (R[K * 3 + J] - R[J * 3 + K]) * t;                \
+        q[1 + I] = vi;                                           \
+        q[1 + J] = (R[J * 3 + I] + R[I * 3 + J]) * t;            \
+        q[1 + K] = (R[K * 3 + I] + R[I * 3 + K]) * t;            \
+    }
+        if (i == 0)
+            R2Q_CASE(0, 1, 2)
+        else if (i == 1)
+            R2Q_CASE(1, 2, 0)
+        else
+            R2Q_CASE(2, 0, 1)
+#undef R2Q_CASE
     }
 }
 /* pose_out = SE3Quat::exp(u) * pose_in   (VertexSE3Expmap::oplusImpl) */
@@ -127,10 +137,13 @@ __device__ __forceinline__ void se3_exp_mul(const double u[6], const double *pin
     const double theta = sqrt(wx * wx + wy * wy + wz * wz);
     const double O[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
     double O2[9];
+#pragma unroll
     for (int i = 0; i < 3; i++)
+#pragma unroll
         for (int j = 0; j < 3; j++) O2[i * 3 + j] = O[i * 3] * O[j] + O[i * 3 + 1] * O[3 + j] + O[i * 3 + 2] * O[6 + j];
     double R[9], V[9];
     if (theta < 0.00001) {
+#pragma unroll
         for (int i = 0; i < 9; i++) {
             R[i] = (i % 4 == 0 ? 1.0 : 0.0) + O[i] + O2[i];
             V[i] = R[i];
@@ -138,6 +151,7 @@ __device__ __forceinline__ void se3_exp_mul(const double u[6], const double *pin
     } else {
         const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta),
                      c = (theta - sin(theta)) / (theta * theta * theta);
+#pragma unroll
         for (int i = 0; i < 9; i++) {
             R[i] = (i % 4 == 0 ? 1.0 : 0.0) + a * O[i] + b * O2[i];
             V[i] = (i % 4 == 0 ? 1.0 : 0.0) + b * O[i] + c * O2[i];
@@ -146,6 +160,7 @@ __device__ __forceinline__ void se3_exp_mul(const double u[6], const double *pin
     double qe[4], te[3];
     R_to_quat(R, qe);
     quat_normalize(qe);
+#pragma unroll
     for (int i = 0; i < 3; i++) te[i] = V[i * 3] * u[3] + V[i * 3 + 1] * u[4] + V[i * 3 + 2] * u[5];
     double RE[9];
     quat_to_R(qe, RE);
@@ -156,7 +171,9 @@ __device__ __forceinline__ void se3_exp_mul(const double u[6], const double *pin
     qo[2] = qe[0] * qi[2] - qe[1] * qi[3] + qe[2] * qi[0] + qe[3] * qi[1];
     qo[3] = qe[0] * qi[3] + qe[1] * qi[2] - qe[2] * qi[1] + qe[3] * qi[0];
     quat_normalize(qo);
+#pragma unroll
     for (int i = 0; i < 4; i++) pout[i] = qo[i];
+#pragma unroll
     for (int i = 0; i < 3; i++) pout[4 + i] = te[i] + RE[i * 3] * ti[0] + RE[i * 3 + 1] * ti[1] + RE[i * 3 + 2] * ti[2];
 }
 __device__ __forceinline__ void project_err(const double *pose, const double *X, const double *ob, double fx, double fy,
