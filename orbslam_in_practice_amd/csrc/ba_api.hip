@@ -294,7 +294,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
     } while (0)
 
 __device__ int g_chol_scalar = 0; /* debug: 1 = plain loops instead of MFMA */
-__device__ bool ba_chol_solve(const BAWin &w, double *D, const int32_t *I, int n, double *dyn, BAShared &s) {
+__device__ __noinline__ bool ba_chol_solve(const BAWin &w, double *D, const int32_t *I, int n, double *dyn, BAShared &s) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); /* uniform: scalar unit */
     const int np = (n + 15) & ~15, nb = np >> 4;
     double *A = D + w.A;
