@@ -291,7 +291,7 @@ static int build_geom(OrbExtractor *h, int w, int hgt) {
         }
         L.out_cap = std::max(L.quota + 4, 4 * L.nIni);
         if (L.out_cap > ORB_QT_MAX_NODES) {
-            g_err = "per-level feature quota exceeds the quadtree list capacity (1020)";
+            g_err = "per-level feature quota exceeds the quadtree list capacity (2044)";
             return ORB_E_INVALID;
         }
         key_off += align_up(L.key_cap, 64);

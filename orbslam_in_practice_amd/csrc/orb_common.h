@@ -12,7 +12,7 @@
 #define ORB_EDGE_THRESHOLD 19
 #define ORB_MIN_BORDER 16      /* EDGE_THRESHOLD - 3, reference src/ORBextractor.cpp:729 */
 #define ORB_CELL_MAX 66        /* FAST cell ROI is at most (59+6) px on a side            */
-#define ORB_QT_MAX_NODES 1024  /* quadtree list capacity per (frame, level)               */
+#define ORB_QT_MAX_NODES 2048  /* quadtree list capacity per (frame, level): k_quadtree<2048>  */
 #define ORB_QT_THREADS 512
 
 /* packed FAST candidate: window-relative x (12 bit) | y (12 bit) << 12 | score << 24 */

@@ -470,7 +470,8 @@ template <int NN> static hipError_t launch_qt(const OrbGeom &g, const OrbBuffers
     dim3 grid(g.nlevels, n_frames);
     /* few frames per call = latency mode: reserve LDS for the key ping-pong of a level (a big batch keeps the keys
        in global memory -- 2048 workgroups holding 100 KB of LDS each would starve the kernels running beside them) */
-    const size_t room = 128 * 1024 - ((sizeof(QtShared<NN>) + 15) & ~(size_t)15); /* keep the workgroup under 128 KB of LDS */
+    const size_t fixed = (sizeof(QtShared<NN>) + 15) & ~(size_t)15;
+    const size_t room = fixed < 128 * 1024 ? 128 * 1024 - fixed : 0; /* keep the workgroup under 128 KB of LDS */
     const int lds_keys = n_frames <= 8 ? (int)std::min<size_t>(12288, room / 8) : 0;
     const size_t lds = ((sizeof(QtShared<NN>) + 15) & ~(size_t)15) + (size_t)lds_keys * 8;
     static PerDeviceLdsLimit lim2;
@@ -489,6 +490,7 @@ hipError_t launch_quadtree(const OrbGeom &g, const OrbBuffers &b, int n_frames, 
     /* few frames per call (latency mode): the widest workgroup -- 8 wavefronts walk the nodes of a pass side by
        side, 0.22 -> 0.11 ms for one 640x480 frame; a big batch has thousands of workgroups in flight and does
        better with the narrow ones */
+    if (need > 1024) return launch_qt<2048>(g, b, n_frames, st); /* > 1020 features on one level: the 1024-thread variant */
     if (n_frames <= 8) return launch_qt<1024>(g, b, n_frames, st);
     if (need <= 256) return launch_qt<256>(g, b, n_frames, st);
     if (need <= 512) return launch_qt<512>(g, b, n_frames, st);

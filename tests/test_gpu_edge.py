@@ -32,7 +32,8 @@ def test_tall_image_reports_aspect_error():
     assert ei.value.code == oa._lib.ORB_E_ASPECT
 
 
-@pytest.mark.parametrize("nf,nlevels,scale", [(50, 8, 1.2), (4000, 8, 1.2), (1000, 4, 1.5), (1000, 1, 1.2), (300, 12, 1.1)])
+@pytest.mark.parametrize("nf,nlevels,scale", [(50, 8, 1.2), (4000, 8, 1.2), (1000, 4, 1.5), (1000, 1, 1.2), (300, 12, 1.1),
+                                             (2000, 2, 1.3), (2000, 1, 1.2)])  # the last two: > 1020 features on one level
 def test_feature_counts_and_pyramid_shapes(oracle, nf, nlevels, scale):
     import orbslam_in_practice_amd as oa
     from orbslam_in_practice_amd import synth
