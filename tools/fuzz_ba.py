@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Randomised BA parity sweep against the CPU oracle: random window sizes, fixed-camera sets, outlier fractions,
+schedules, robust on/off, shuffled camera order; estimates within 1e-5 relative, outlier labels equal.
+Usage: python tools/fuzz_ba.py [n_configs] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import orbslam_in_practice_amd as oa  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+from orbslam_in_practice_amd import synth  # noqa: E402
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def main():
+    n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
+    opt = oa.Optimizer(max_cams=128, max_points=8192, max_obs=80000, max_batch=4)
+    bad = 0
+    for c in range(n_cfg):
+        nc = int(rng.integers(3, 110))
+        npt = int(rng.integers(30, 60 * nc + 60))
+        w = synth.make_ba_window(int(rng.integers(1 << 30)), nc, min(npt, 6000), outlier_frac=float(rng.choice([0.0, 0.05, 0.15])))
+        nfix = int(rng.integers(2, max(3, nc // 3)))
+        w["fixed"][:] = 0
+        w["fixed"][rng.permutation(nc)[:nfix]] = 1
+        if rng.integers(0, 2):  # shuffle the camera order (irregular Cholesky envelope)
+            perm = rng.permutation(nc)
+            inv = np.empty(nc, np.int64)
+            inv[perm] = np.arange(nc)
+            w["poses"], w["fixed"] = w["poses"][perm].copy(), w["fixed"][perm].copy()
+            w["cam_idx"] = inv[w["cam_idx"]].astype(np.int32)
+        rounds = [(5, 10), (10,), (3, 3, 3), (5, 10)][int(rng.integers(0, 4))]
+        robust = bool(rng.integers(0, 4) > 0)
+        ref = orc.ba_solve(w, rounds=rounds, robust=robust)
+        got = opt.solve_batch([w], rounds, robust=robust)[0]
+        ok = (got["iterations"] == ref["iterations"] and np.array_equal(got["outlier"], ref["outlier"]) and
+              rel(got["points"], ref["points"]) < 1e-5 and rel(got["poses"][:, 4:], ref["poses"][:, 4:]) < 1e-5 and
+              abs(got["chi2_final"] - ref["chi2_final"]) <= 1e-6 * max(ref["chi2_final"], 1e-30))
+        bad += 0 if ok else 1
+        print("cfg %2d cams %3d (fixed %2d) points %4d obs %5d rounds %s robust %d  %s  rel(points) %.1e" % (
+            c, nc, nfix, len(w["points"]), len(w["obs"]), rounds, robust, "ok" if ok else "MISMATCH",
+            rel(got["points"], ref["points"])), flush=True)
+    print("FUZZ-BA %s: %d mismatches in %d configs" % ("FAILED" if bad else "OK", bad, n_cfg))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
