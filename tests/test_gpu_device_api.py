@@ -103,3 +103,51 @@ def test_strided_and_unaligned_device_input(oracle):
                                  d_cnt.data_ptr(), None)
     assert ei.value.code == oa._lib.ORB_E_CAPACITY
     ext.close()
+
+
+def test_measurement_hooks_report_every_stage():
+    """orb_set_profiling / orb_get_stage_ms and orb_matcher_set_profiling / orb_matcher_get_stage_ms (what
+    bench.py's roofline is built from): HIP events on the caller's stream, every stage a positive duration, the
+    matcher's two phases adding up to its total"""
+    import orbslam_in_practice_amd as oa
+    from orbslam_in_practice_amd import shard, synth
+    B, W, H = 4, 640, 480
+    L = oa._lib.lib()
+    dev = torch.device("cuda", 0)
+    ext = oa.ORBextractor(1000, 1.2, 8, 20, 7, max_w=W, max_h=H, max_batch=B)
+    cap = ext.cap
+    m = oa.ORBmatcher(0.9, True, max_keypoints=cap, max_pairs=B)
+    d_img = torch.from_numpy(synth.make_stream(5, B, W, H)).to(dev)
+    d_kps = torch.zeros((B, cap, 28), dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros((B,), dtype=torch.int32, device=dev)
+    pa_h, pb_h = shard.stream_pairs(0, 1, B)
+    pa, pb = torch.from_numpy(pa_h).to(dev), torch.from_numpy(pb_h).to(dev)
+    d_m12 = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+    d_nm = torch.zeros((B,), dtype=torch.int32, device=dev)
+    st = torch.cuda.Stream(device=dev)
+    sp = C.c_void_p(st.cuda_stream)
+    oa._lib.check(L.orb_set_profiling(ext._h, 1))
+    oa._lib.check(L.orb_matcher_set_profiling(m._m, 1))
+    for _ in range(3):
+        ext.extract_batch_device(d_img.data_ptr(), B, W, H, W, W * H, d_kps.data_ptr(), d_desc.data_ptr(), cap,
+                                 d_cnt.data_ptr(), sp)
+        m.match_batch_device(d_kps.data_ptr(), d_desc.data_ptr(), d_cnt.data_ptr(), cap, pa.data_ptr(), pb.data_ptr(), B,
+                             (0.0, float(W), 0.0, float(H)), -1, d_m12.data_ptr(), d_nm.data_ptr(), sp)
+    torch.cuda.synchronize()
+    ms5 = (C.c_float * 5)()
+    oa._lib.check(L.orb_get_stage_ms(ext._h, ms5))
+    assert all(0.0 < float(v) < 50.0 for v in ms5), list(ms5)
+    ms2 = (C.c_float * 2)()
+    oa._lib.check(L.orb_matcher_get_stage_ms(m._m, ms2))
+    assert 0.0 < ms2[0] < 50.0 and 0.0 < ms2[1] < 50.0
+    # the ring was consumed by the call above: a second read has nothing to average
+    assert L.orb_matcher_get_stage_ms(m._m, ms2) == oa._lib.ORB_E_INVALID
+    for _ in range(2):
+        m.match_batch_device(d_kps.data_ptr(), d_desc.data_ptr(), d_cnt.data_ptr(), cap, pa.data_ptr(), pb.data_ptr(), B,
+                             (0.0, float(W), 0.0, float(H)), -1, d_m12.data_ptr(), d_nm.data_ptr(), sp)
+    tot = C.c_float(0)
+    oa._lib.check(L.orb_matcher_get_ms(m._m, C.byref(tot)))
+    assert 0.0 < tot.value < 50.0
+    m.close()
+    ext.close()
