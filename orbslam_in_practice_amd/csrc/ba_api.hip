@@ -1848,13 +1848,21 @@ extern "C" int ba_pose_optimization_batch(BASolver *s, double *poses, const doub
            *d_info = d_obs + (size_t)n * 2;
     uint8_t *d_fl = s->dB, *d_out = s->dB + n + 8;
     int32_t *d_offs = s->dI, *d_ninl = s->dI + n_problems + 1;
-    BCHK(hipMemcpyAsync(d_pose, poses, (size_t)n_problems * 56, hipMemcpyHostToDevice, s->stream));
-    BCHK(hipMemcpyAsync(d_offs, offsets, (size_t)(n_problems + 1) * 4, hipMemcpyHostToDevice, s->stream));
+    /* inputs: packed in the pinned staging buffers in the device layout and sent as ONE copy per buffer (five copies
+       from pageable memory each cost a blocking bounce; Tracking calls this up to three times per frame) */
+    const size_t npose = ((size_t)n_problems * 7 + 1) & ~(size_t)1, nD_in = npose + (size_t)n * 6;
+    if ((rc = ba_grow_pinned(s->pD, s->pcapD, nD_in))) return rc;
+    if ((rc = ba_grow_pinned(s->pI, s->pcapI, (size_t)2 * n_problems + 4))) return rc;
+    if ((rc = ba_grow_pinned(s->pB, s->pcapB, std::max<size_t>((size_t)n, 1)))) return rc;
+    memcpy(s->pD, poses, (size_t)n_problems * 56);
     if (n > 0) {
-        BCHK(hipMemcpyAsync(d_xw, xw, (size_t)n * 24, hipMemcpyHostToDevice, s->stream));
-        BCHK(hipMemcpyAsync(d_obs, obs, (size_t)n * 16, hipMemcpyHostToDevice, s->stream));
-        BCHK(hipMemcpyAsync(d_info, inv_sigma2, (size_t)n * 8, hipMemcpyHostToDevice, s->stream));
+        memcpy(s->pD + npose, xw, (size_t)n * 24);
+        memcpy(s->pD + npose + (size_t)n * 3, obs, (size_t)n * 16);
+        memcpy(s->pD + npose + (size_t)n * 5, inv_sigma2, (size_t)n * 8);
     }
+    memcpy(s->pI, offsets, (size_t)(n_problems + 1) * 4);
+    BCHK(hipMemcpyAsync(d_pose, s->pD, nD_in * 8, hipMemcpyHostToDevice, s->stream));
+    BCHK(hipMemcpyAsync(d_offs, s->pI, (size_t)(n_problems + 1) * 4, hipMemcpyHostToDevice, s->stream));
     int maxe = 0;
     for (int p = 0; p < n_problems; p++) maxe = std::max(maxe, offsets[p + 1] - offsets[p]);
     int lds_edges = 0;
@@ -1869,10 +1877,13 @@ extern "C" int ba_pose_optimization_batch(BASolver *s, double *poses, const doub
                        (const double *)d_obs, (const double *)d_info, d_fl, d_out, (const int32_t *)d_offs, fx, fy, cx, cy,
                        d_ninl, lds_edges);
     BCHK(hipGetLastError());
-    BCHK(hipMemcpyAsync(poses, d_pose, (size_t)n_problems * 56, hipMemcpyDeviceToHost, s->stream));
-    if (n > 0) BCHK(hipMemcpyAsync(outlier, d_out, (size_t)n, hipMemcpyDeviceToHost, s->stream));
-    BCHK(hipMemcpyAsync(n_inliers, d_ninl, (size_t)n_problems * 4, hipMemcpyDeviceToHost, s->stream));
+    BCHK(hipMemcpyAsync(s->pD, d_pose, (size_t)n_problems * 56, hipMemcpyDeviceToHost, s->stream));
+    if (n > 0) BCHK(hipMemcpyAsync(s->pB, d_out, (size_t)n, hipMemcpyDeviceToHost, s->stream));
+    BCHK(hipMemcpyAsync(s->pI + n_problems + 1, d_ninl, (size_t)n_problems * 4, hipMemcpyDeviceToHost, s->stream));
     BCHK(hipStreamSynchronize(s->stream));
+    memcpy(poses, s->pD, (size_t)n_problems * 56);
+    if (n > 0) memcpy(outlier, s->pB, (size_t)n);
+    memcpy(n_inliers, s->pI + n_problems + 1, (size_t)n_problems * 4);
     return ORB_OK;
 }
 
