@@ -1599,7 +1599,7 @@ __device__ __forceinline__ void po_reduce(double *v, int nv, POShared &s, double
     }
 }
 
-__device__ double po_chi2(const double *pose, const double *xw, const double *obs, const double *info, const uint8_t *fl,
+__device__ __forceinline__ double po_chi2(const double *pose, const double *xw, const double *obs, const double *info, const uint8_t *fl,
                           int n, double fx, double fy, double cx, double cy, double delta, POShared &s) {
     double acc = 0;
     for (int i = threadIdx.x; i < n; i += PO_T) {
@@ -1680,7 +1680,11 @@ __global__ __launch_bounds__(PO_T) void k_pose_opt(double *pose7_all, const doub
         return;
     }
     const double delta = 5.99;
-    if (tid < 7) s.pose[tid] = pose7[tid];
+    /* the pose lives in registers, identical in every thread (all of them run the same deterministic update), so
+       neither the exponential map nor an accepted step needs LDS broadcasts and their barriers */
+    double pose[7], trial[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) pose[i] = pose7[i];
     if (n <= lds_edges) {
         /* the 40 iterations make ~120 passes over the same few hundred edges, each a dependent trip to L2/HBM per
            loop step: stage the correspondences (48 B each) and their flags in LDS once -- same arithmetic, same
@@ -1700,8 +1704,7 @@ __global__ __launch_bounds__(PO_T) void k_pose_opt(double *pose7_all, const doub
         outlier[i] = 0;
     }
     __syncthreads();
-    if (tid == 0) quat_normalize(s.pose);
-    __syncthreads();
+    quat_normalize(pose);
     int nBads = 0;
     double lambda = 0, ni = 2;
     for (int it = 0; it < 4; it++) {
@@ -1711,7 +1714,7 @@ __global__ __launch_bounds__(PO_T) void k_pose_opt(double *pose7_all, const doub
         for (int k = 0; k < 10 && ok; k++) {
             /* the chi2 of the current pose is the trial chi2 of the step that was just accepted (same pose, same
                flags, same summation order): only the first step of a round has to evaluate it */
-            if (!have_chi) currentChi = po_chi2(s.pose, xw, obs, info, fl, n, fx, fy, cx, cy, delta, s);
+            if (!have_chi) currentChi = po_chi2(pose, xw, obs, info, fl, n, fx, fy, cx, cy, delta, s);
             have_chi = true;
             double acc[28];
 #pragma unroll
@@ -1719,8 +1722,8 @@ __global__ __launch_bounds__(PO_T) void k_pose_opt(double *pose7_all, const doub
             for (int i = tid; i < n; i += PO_T) {
                 if (!(fl[i] & 1)) continue;
                 double e[2], pc[3], Ji[6], Jj[12];
-                project_err(s.pose, xw + (int64_t)i * 3, obs + (int64_t)i * 2, fx, fy, cx, cy, e, pc);
-                jacobians(s.pose, pc, fx, fy, Ji, Jj);
+                project_err(pose, xw + (int64_t)i * 3, obs + (int64_t)i * 2, fx, fy, cx, cy, e, pc);
+                jacobians(pose, pc, fx, fy, Ji, Jj);
                 double wgt = info[i], r0 = -wgt * e[0], r1 = -wgt * e[1];
                 if (fl[i] & 2) {
                     const double rw = huber_w((e[0] * e[0] + e[1] * e[1]) * info[i], delta);
@@ -1767,15 +1770,13 @@ __global__ __launch_bounds__(PO_T) void k_pose_opt(double *pose7_all, const doub
                 /* every thread solves the same 6x6 system redundantly (uniform, no broadcast needed) */
                 double x[6];
                 const bool ok2 = po_chol6_solve(H, lambda, b, x);
-                __syncthreads();
-                if (tid == 0) {
-                    if (ok2)
-                        se3_exp_mul(x, s.pose, s.trial);
-                    else
-                        for (int i = 0; i < 7; i++) s.trial[i] = s.pose[i];
+                if (ok2) {
+                    se3_exp_mul(x, pose, trial);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 7; i++) trial[i] = pose[i];
                 }
-                __syncthreads();
-                double tempChi = po_chi2(s.trial, xw, obs, info, fl, n, fx, fy, cx, cy, delta, s);
+                double tempChi = po_chi2(trial, xw, obs, info, fl, n, fx, fy, cx, cy, delta, s);
                 if (!ok2) tempChi = 1.7976931348623157e308;
                 double scale = 0;
                 if (ok2)
@@ -1789,9 +1790,8 @@ __global__ __launch_bounds__(PO_T) void k_pose_opt(double *pose7_all, const doub
                     lambda *= fmax(1. / 3., alpha);
                     ni = 2;
                     currentChi = tempChi;
-                    __syncthreads();
-                    if (tid < 7) s.pose[tid] = s.trial[tid];
-                    __syncthreads();
+#pragma unroll
+                    for (int i = 0; i < 7; i++) pose[i] = trial[i];
                 } else {
                     lambda *= ni;
                     ni *= 2;
@@ -1804,7 +1804,7 @@ __global__ __launch_bounds__(PO_T) void k_pose_opt(double *pose7_all, const doub
         double bad = 0;
         for (int i = tid; i < n; i += PO_T) {
             double e[2], pc[3];
-            project_err(s.pose, xw + (int64_t)i * 3, obs + (int64_t)i * 2, fx, fy, cx, cy, e, pc);
+            project_err(pose, xw + (int64_t)i * 3, obs + (int64_t)i * 2, fx, fy, cx, cy, e, pc);
             const double c = (e[0] * e[0] + e[1] * e[1]) * info[i];
             uint8_t f = fl[i];
             if (c > 5.991) {
@@ -1824,7 +1824,10 @@ __global__ __launch_bounds__(PO_T) void k_pose_opt(double *pose7_all, const doub
         __syncthreads();
         if (n < 10) break;
     }
-    if (tid < 7) pose7[tid] = s.pose[tid];
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 7; i++) pose7[i] = pose[i];
+    }
     if (tid == 0) *n_inliers = n - nBads;
 }
 
