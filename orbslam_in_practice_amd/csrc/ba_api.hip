@@ -1599,6 +1599,31 @@ __device__ __forceinline__ void po_reduce(double *v, int nv, POShared &s, double
     }
 }
 
+/* Sum of 28 per-thread partials (the 21 + 6 entries of H and b, and the active-edge count) over the workgroup by an
+ * LDS transpose: every thread stores its 28 values, 224 threads each add 32 of them (8 threads per value,
+ * interleaved slices), three shuffle steps finish.  About 0.4 us against 2.8 us for 28 six-step shuffle butterflies
+ * (each f64 step is two LDS-crossbar permutes). */
+#define PO_TR_LD (PO_T + 2)
+__device__ __forceinline__ void po_reduce28(const double *v, double (*tr)[PO_TR_LD], POShared &s, double *out) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 28; i++) tr[i][tid] = v[i];
+    __syncthreads();
+    if (tid < 28 * 8) {
+        const int val = tid >> 3, seg = tid & 7;
+        double t = 0;
+#pragma unroll 8
+        for (int j = 0; j < PO_T / 8; j++) t += tr[val][j * 8 + seg];
+        t += __shfl_xor(t, 1);
+        t += __shfl_xor(t, 2);
+        t += __shfl_xor(t, 4);
+        if (seg == 0) s.red[0][val] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 28; i++) out[i] = s.red[0][i];
+}
+
 __device__ __forceinline__ double po_chi2(const double *pose, const double *xw, const double *obs, const double *info, const uint8_t *fl,
                           int n, double fx, double fy, double cx, double cy, double delta, POShared &s) {
     double acc = 0;
@@ -1667,6 +1692,7 @@ __global__ __launch_bounds__(PO_T) void k_pose_opt(double *pose7_all, const doub
                                                     int32_t *n_inliers_all, int lds_edges) {
     /* one workgroup per pose problem: problem p owns edges [offs[p], offs[p+1]) */
     __shared__ POShared s;
+    __shared__ double po_tr[28][PO_TR_LD];
     extern __shared__ __attribute__((aligned(16))) double po_dyn[];
     const int tid = threadIdx.x;
     const int e0 = offs[blockIdx.x], n = offs[blockIdx.x + 1] - e0;
@@ -1741,7 +1767,7 @@ __global__ __launch_bounds__(PO_T) void k_pose_opt(double *pose7_all, const doub
                 acc[27] += 1.0;
             }
             double tot[28];
-            po_reduce(acc, 28, s, tot);
+            po_reduce28(acc, po_tr, s, tot);
             if (tot[27] == 0.0) break;
             double H[36], b[6];
             {
@@ -1870,7 +1896,7 @@ extern "C" int ba_pose_optimization_batch(BASolver *s, double *poses, const doub
     for (int p = 0; p < n_problems; p++) maxe = std::max(maxe, offsets[p + 1] - offsets[p]);
     int lds_edges = 0;
     const size_t po_lds = ((size_t)maxe * 49 + 15) & ~(size_t)15; /* 6 doubles + 1 flag byte per correspondence */
-    if (maxe > 0 && po_lds <= 128 * 1024) {
+    if (maxe > 0 && po_lds <= 96 * 1024) { /* beside the 58 KB of static LDS of the kernel */
         lds_edges = maxe;
         static PerDeviceLdsLimit po_lim;
         if (po_lim.raise(po_lds))
