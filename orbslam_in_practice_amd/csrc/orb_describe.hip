@@ -119,14 +119,22 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeom g, const uint8_t *pyr,
         const int u = lane - 15;
         if (lane < 31) {
             const uint32_t col = (uint32_t)lane; /* = u + 15 */
-            m10 = u * (int)patch[col + 15u * (uint32_t)pitch];
+            /* all 31 rows of this lane's column are fetched unconditionally (the 31 x 31 square lies inside the
+               image: EDGE_THRESHOLD 19 > 15) and BEFORE any of them is used -- one memory round trip instead of
+               fifteen dependent ones behind the circular-mask branches; the mask is applied to the arithmetic */
+            int vp[16], vm[16];
+            const int ctr = patch[col + 15u * (uint32_t)pitch];
 #pragma unroll
             for (int v = 1; v <= 15; v++) {
-                if (u >= -c_umax[v] && u <= c_umax[v]) {
-                    int vp = patch[col + (uint32_t)(15 + v) * (uint32_t)pitch], vm = patch[col + (uint32_t)(15 - v) * (uint32_t)pitch];
-                    m01 += v * (vp - vm);
-                    m10 += u * (vp + vm);
-                }
+                vp[v] = patch[col + (uint32_t)(15 + v) * (uint32_t)pitch];
+                vm[v] = patch[col + (uint32_t)(15 - v) * (uint32_t)pitch];
+            }
+            m10 = u * ctr;
+#pragma unroll
+            for (int v = 1; v <= 15; v++) {
+                const bool in = u >= -c_umax[v] && u <= c_umax[v];
+                m01 += in ? v * (vp[v] - vm[v]) : 0;
+                m10 += in ? u * (vp[v] + vm[v]) : 0;
             }
         }
 #pragma unroll
