@@ -293,8 +293,16 @@ __global__ __launch_bounds__(64) void k_match_init(MatchArgs A) {
         m12[i] = -1;
         bins[i] = 0xFF;
     }
-    if (A.desc_in_lds)
-        for (int i = lane; i < n2 * 2; i += 64) s_desc[i] = ((const uint4 *)D2)[i];
+    if (A.desc_in_lds) { /* eight 16-byte loads in flight per lane before the first LDS store */
+        for (int i0 = lane; i0 < n2 * 2; i0 += 64 * 8) {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = (i0 + u * 64 < n2 * 2) ? ((const uint4 *)D2)[i0 + u * 64] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (i0 + u * 64 < n2 * 2) s_desc[i0 + u * 64] = v[u];
+        }
+    }
     if (lane < HISTO_LENGTH) s_hist[lane] = 0;
     __syncthreads();
     const float r = (float)A.window;

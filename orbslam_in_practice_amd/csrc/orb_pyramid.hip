@@ -203,17 +203,38 @@ __global__ __launch_bounds__(256) void k_blur(OrbGeom g, const uint8_t *pyr, uin
     uint8_t *dst = level_ptr(blur, g, frame, level);
     const int tid = threadIdx.x;
     const bool interior = tx0 >= 4 && tx0 + BL_TW + 4 <= L.w; /* every staged byte is a real pixel of its row */
+    /* staging: every load of a thread is issued before the first LDS store (one memory round trip per tile instead
+       of one per loop step) */
     if (interior) {
-        for (int i = tid; i < (BL_TH + 6) * 18; i += 256) {
+        constexpr int NI = ((BL_TH + 6) * 18 + 255) / 256;
+        uint32_t v[NI];
+#pragma unroll
+        for (int k = 0; k < NI; k++) {
+            const int i = tid + k * 256;
             const int r = i / 18, c4 = i - r * 18;
-            const int y = reflect101(ty0 + r - 3, L.h);
-            *(uint32_t *)&s_in[r][c4 * 4] = *(const uint32_t *)(src + __mul24(y, L.pitch) + (tx0 - 4) + c4 * 4);
+            const int y = reflect101(ty0 + min(r, BL_TH + 5) - 3, L.h);
+            v[k] = (i < (BL_TH + 6) * 18) ? *(const uint32_t *)(src + __mul24(y, L.pitch) + (tx0 - 4) + c4 * 4) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < NI; k++) {
+            const int i = tid + k * 256;
+            const int r = i / 18, c4 = i - r * 18;
+            if (i < (BL_TH + 6) * 18) *(uint32_t *)&s_in[r][c4 * 4] = v[k];
         }
     } else {
-        for (int i = tid; i < (BL_TH + 6) * (BL_TW + 8); i += 256) {
-            const int r = i / (BL_TW + 8), c = i - r * (BL_TW + 8);
+        constexpr int NB = ((BL_TH + 6) * (BL_TW + 8) + 255) / 256;
+        uint8_t v[NB];
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const int i = tid + k * 256;
+            const int r = min(i / (BL_TW + 8), BL_TH + 5), c = i - (i / (BL_TW + 8)) * (BL_TW + 8);
             const int y = reflect101(ty0 + r - 3, L.h), x = reflect101(tx0 - 4 + c, L.w);
-            s_in[r][c] = src[__mul24(y, L.pitch) + x];
+            v[k] = src[__mul24(y, L.pitch) + x];
+        }
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const int i = tid + k * 256;
+            if (i < (BL_TH + 6) * (BL_TW + 8)) s_in[i / (BL_TW + 8)][i - (i / (BL_TW + 8)) * (BL_TW + 8)] = v[k];
         }
     }
     __syncthreads();
