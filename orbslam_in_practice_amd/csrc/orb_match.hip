@@ -278,16 +278,23 @@ __global__ __launch_bounds__(64) void k_match_init(MatchArgs A) {
     const bool brute = A.window < 0;
     const float invW = (float)GRID_COLS / (A.max_x - A.min_x); /* src/Frame.cpp:59-60 */
     const float invH = (float)GRID_ROWS / (A.max_y - A.min_y);
-    for (int j = lane; j < n2; j += 64) {
-        const OrbKeyPoint kp = k2[j];
-        s_x[j] = kp.x;
-        s_y[j] = kp.y;
-        s_ang[j] = kp.angle;
-        const uint32_t ord = f2_order_key(kp, j, brute, A.min_x, A.min_y, invW, invH);
-        s_ord[j] = ord;
-        s_m21[j] = -1;
-        s_md[j] = 0xFFFF;
-        s_stamp[j] = 0x7FFFFFFF;
+    for (int j0 = lane; j0 < n2; j0 += 64 * 4) { /* four keypoints per lane in flight before the LDS stores */
+        OrbKeyPoint kp[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) kp[u] = k2[min(j0 + u * 64, n2 - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + u * 64;
+            if (j < n2) {
+                s_x[j] = kp[u].x;
+                s_y[j] = kp[u].y;
+                s_ang[j] = kp[u].angle;
+                s_ord[j] = f2_order_key(kp[u], j, brute, A.min_x, A.min_y, invW, invH);
+                s_m21[j] = -1;
+                s_md[j] = 0xFFFF;
+                s_stamp[j] = 0x7FFFFFFF;
+            }
+        }
     }
     for (int i = lane; i < n1; i += 64) {
         m12[i] = -1;
