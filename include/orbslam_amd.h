@@ -66,7 +66,10 @@ int orb_get_tables(const OrbExtractor *h, float *scale, float *inv_scale, float 
                    int32_t *features_per_level, int32_t *umax16);
 /* pyramid level sizes for a w x h input (src/ORBextractor.cpp:1075-1077) */
 int orb_get_level_sizes(const OrbExtractor *h, int w, int hgt, int32_t *ws, int32_t *hs);
-/* worst-case number of keypoints one frame can return (sum over levels of quota + slack) */
+/* worst-case number of keypoints one frame can return: per level max(quota + 4, 4 * nIni), nIni = round(W / H) quadtree
+ * roots (src/ORBextractor.cpp:493-534 -- a wide frame with a small budget returns more than its budget).  The bound is
+ * that of the frame size the handle currently holds: the creation size until a call with another size, after which
+ * (also after an ORB_E_CAPACITY from such a call) it reports the new one. */
 int orb_max_keypoints(const OrbExtractor *h);
 
 /* ---- ORBextractor::operator() (replaces src/ORBextractor.cpp:1001-1065) -------------------------

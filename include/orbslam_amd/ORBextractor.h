@@ -61,11 +61,21 @@ class ORBextractor {
         cv::Mat img = image.getMat();
         assert(img.type() == CV_8UC1); /* :1008 */
         static_assert(sizeof(cv::KeyPoint) == sizeof(OrbKeyPoint), "cv::KeyPoint must be the 28-byte POD");
-        kp_buf_.resize(cap_);
-        desc_buf_.resize((size_t)cap_ * 32);
         int32_t n = 0;
-        int rc = orb_extract(h_, img.data, img.cols, img.rows, (int)img.step, (OrbKeyPoint *)kp_buf_.data(),
+        int rc = ORB_OK;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            kp_buf_.resize(cap_);
+            desc_buf_.resize((size_t)cap_ * 32);
+            rc = orb_extract(h_, img.data, img.cols, img.rows, (int)img.step, (OrbKeyPoint *)kp_buf_.data(),
                              desc_buf_.data(), cap_, &n);
+            /* a frame shape with a larger bound than the creation size (wide frames: 4 * nIni keypoints per level):
+               the handle now holds its geometry, ask again and retry once */
+            if (rc == ORB_E_CAPACITY && attempt == 0 && orb_max_keypoints(h_) > cap_) {
+                cap_ = orb_max_keypoints(h_);
+                continue;
+            }
+            break;
+        }
         if (rc != ORB_OK) throw std::runtime_error(std::string("ORBextractor: ") + orb_last_error());
         last_w_ = img.cols;
         last_h_ = img.rows;

@@ -140,7 +140,8 @@ class OrbOracle:
     def extract(self, img, trig=TRIG_DET, cap=None):
         img = np.ascontiguousarray(img, np.uint8)
         h, w = img.shape
-        cap = cap or (self.cfg.nfeatures + 4 * self.nlevels + 64)
+        # per level the quadtree returns up to max(quota + 3, 4 * nIni) keypoints, nIni = round(W / H) roots (wide images)
+        cap = cap or (self.cfg.nfeatures + self.nlevels * (8 + 4 * (w // max(h, 1) + 2)) + 64)
         kps = np.zeros(cap, KP_DTYPE)
         desc = np.zeros((cap, 32), np.uint8)
         n = C.c_int32(0)

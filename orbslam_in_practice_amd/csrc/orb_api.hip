@@ -401,9 +401,13 @@ static int alloc_staging(OrbExtractor *h, int w, int hgt, int batch) {
 
 extern "C" int orb_max_keypoints(const OrbExtractor *h) {
     if (!h) return 0;
-    /* the quadtree stops at >= quota nodes and can overshoot by at most 3 per level */
+    /* per level the quadtree stops at >= quota nodes and can overshoot by at most 3 -- but it never returns fewer
+       than the children of its nIni = round(W / H) root nodes allow, so a wide frame with a small budget can
+       yield up to 4 * nIni keypoints per level (src/ORBextractor.cpp:493-534).  The bound is that of the frame
+       size the handle currently holds (the creation size until a call brings another one). */
     int tot = 0;
     for (int l = 0; l < h->cfg.nlevels; l++) tot += h->nfeat[l] + 4;
+    if (h->geom_valid) tot = std::max(tot, h->geom.total_out_cap);
     return tot;
 }
 
@@ -556,13 +560,13 @@ extern "C" int orb_extract_batch_device(OrbExtractor *h, const uint8_t *d_imgs, 
         g_err = "orb_extract_batch_device: bad argument";
         return ORB_E_INVALID;
     }
-    if (cap < orb_max_keypoints(h)) {
-        g_err = "orb_extract_batch_device: cap must be >= orb_max_keypoints()";
-        return ORB_E_CAPACITY;
-    }
     HIPCHK(hipSetDevice(h->device));
     int rc;
     if ((rc = set_geometry(h, w, hgt))) return rc;
+    if (cap < orb_max_keypoints(h)) { /* the bound of THIS frame size (wide frames: 4 * nIni per level) */
+        g_err = "orb_extract_batch_device: cap must be >= orb_max_keypoints() for this frame size";
+        return ORB_E_CAPACITY;
+    }
     if ((rc = ensure_buffers(h, n_frames))) return rc;
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     const OrbGeom &g = h->geom;
@@ -625,6 +629,10 @@ extern "C" int orb_extract_batch(OrbExtractor *h, const uint8_t *const *imgs, in
         if ((rc = alloc_staging(h, std::max(w, h->max_w), std::max(hgt, h->max_h), h->max_batch))) return rc;
     }
     if ((rc = set_geometry(h, w, hgt))) return rc;
+    if (orb_max_keypoints(h) > h->out_cap) { /* this frame shape can return more keypoints than the staging holds */
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if ((rc = alloc_staging(h, h->max_w, h->max_h, h->max_batch))) return rc;
+    }
     const int pitch = h->geom.lv[0].pitch;
     const size_t fbytes = (size_t)pitch * hgt;
     for (int f = 0; f < n_frames; f++)

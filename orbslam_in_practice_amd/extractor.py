@@ -80,23 +80,41 @@ class ORBextractor:
         if image.strides[1] != 1:
             image = np.ascontiguousarray(image)
         h, w = image.shape
-        kps = np.zeros(self.cap, KP_DTYPE)
-        desc = np.zeros((self.cap, 32), np.uint8)
-        n = C.c_int32(0)
-        check(self._L.orb_extract(self._h, ptr(image), w, h, image.strides[0], ptr(kps), ptr(desc), self.cap,
-                                  C.byref(n)))
+        for attempt in (0, 1):
+            kps = np.zeros(self.cap, KP_DTYPE)
+            desc = np.zeros((self.cap, 32), np.uint8)
+            n = C.c_int32(0)
+            rc = self._L.orb_extract(self._h, ptr(image), w, h, image.strides[0], ptr(kps), ptr(desc), self.cap,
+                                     C.byref(n))
+            if rc == _lib.ORB_E_CAPACITY and attempt == 0 and self._grow_cap():
+                continue  # a frame shape whose bound (4 * nIni per level for wide frames) exceeds the creation size's
+            check(rc)
+            break
         self._wh = (w, h)
         return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def _grow_cap(self):
+        """orb_max_keypoints() follows the frame size the handle last saw"""
+        cap = self._L.orb_max_keypoints(self._h)
+        if cap > self.cap:
+            self.cap = cap
+            return True
+        return False
 
     def extract_batch(self, images):
         """images: [B,H,W] u8 (host).  Returns list of (kps, desc)."""
         images = np.ascontiguousarray(images, np.uint8)
         B, h, w = images.shape
         ptrs = (C.c_void_p * B)(*[images[i].ctypes.data for i in range(B)])
-        kps = np.zeros((B, self.cap), KP_DTYPE)
-        desc = np.zeros((B, self.cap, 32), np.uint8)
-        n = np.zeros(B, np.int32)
-        check(self._L.orb_extract_batch(self._h, ptrs, B, w, h, w, ptr(kps), ptr(desc), self.cap, ptr(n)))
+        for attempt in (0, 1):
+            kps = np.zeros((B, self.cap), KP_DTYPE)
+            desc = np.zeros((B, self.cap, 32), np.uint8)
+            n = np.zeros(B, np.int32)
+            rc = self._L.orb_extract_batch(self._h, ptrs, B, w, h, w, ptr(kps), ptr(desc), self.cap, ptr(n))
+            if rc == _lib.ORB_E_CAPACITY and attempt == 0 and self._grow_cap():
+                continue
+            check(rc)
+            break
         self._wh = (w, h)
         return [(kps[i, :n[i]].copy(), desc[i, :n[i]].copy()) for i in range(B)]
 

@@ -152,3 +152,23 @@ def test_error_text_of_matcher_and_ba_reaches_orb_last_error():
     assert ei.value.code == oa._lib.ORB_E_CAPACITY and "16384" in str(ei.value)
     m.close()
     del k1, k2
+
+
+@pytest.mark.parametrize("w,h,nf,nl,nb", [(1346, 154, 100, 7, 3), (1008, 155, 100, 5, 1), (900, 120, 50, 4, 2)])
+def test_wide_frames_return_more_than_their_budget(oracle, w, h, nf, nl, nb):
+    """nIni = round(W / H) quadtree roots (src/ORBextractor.cpp:493-534): a wide frame with a small feature budget
+    returns up to 4 * nIni keypoints per level -- several times nfeatures.  The capacity bound has to follow the
+    frame shape (orb_max_keypoints), in the batch and in the single-frame (latency) path, and through a handle that
+    was created for another shape."""
+    import orbslam_in_practice_amd as oa
+    from orbslam_in_practice_amd import synth
+    frames = np.stack([synth.make_frame(1000 + i, w, h, n_shapes=2000) for i in range(nb)])
+    o = oracle.OrbOracle(nf, 1.2, nl, 20, 3)
+    want = [o.extract(f) for f in frames]
+    assert max(len(k) for k, _ in want) > nf + 4 * nl      # more than the naive sum of quotas
+    for create_w, create_h in ((w, h), (640, 480)):
+        e = oa.ORBextractor(nf, 1.2, nl, 20, 3, max_w=create_w, max_h=create_h, max_batch=nb)
+        got = e.extract_batch(frames) if nb > 1 else [e(frames[0])]
+        for (k, d), (ok, od) in zip(got, want):
+            assert np.array_equal(k, ok) and np.array_equal(d, od)
+        e.close()
