@@ -2,7 +2,7 @@
 """Randomised parity sweep (not part of the test suite: a few minutes of oracle time): random frame sizes, feature
 budgets, scale factors, pyramid depths and FAST thresholds through the extractor, random window / ratio settings
 through the matcher, single-frame (latency mode) and batched launches, all compared with the CPU oracle bit for bit.
-Usage: python tools/fuzz_parity.py [n_configs] [seed]"""
+Usage: python tools/fuzz_parity.py [n_configs] [seed] [wild]"""
 import os
 import sys
 
@@ -18,12 +18,17 @@ from orbslam_in_practice_amd import synth  # noqa: E402
 def main():
     n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    wild = len(sys.argv) > 3 and sys.argv[3] == "wild"
     bad = 0
     for c in range(n_cfg):
-        w, h = int(rng.integers(120, 1400)), int(rng.integers(100, 800))
-        if w < 0.6 * h:
-            w = h
-        nf = int(rng.choice([100, 500, 1000, 2000, 3000]))
+        if wild:  # extreme shapes and budgets
+            w, h = int(rng.integers(40, 2000)), int(rng.integers(40, 1100))
+            nf = int(rng.choice([5, 30, 100, 700, 1000, 2500, 5000]))
+        else:
+            w, h = int(rng.integers(120, 1400)), int(rng.integers(100, 800))
+            if w < 0.6 * h:
+                w = h
+            nf = int(rng.choice([100, 500, 1000, 2000, 3000]))
         scale = float(rng.choice([1.1, 1.2, 1.2, 1.3, 1.5, 2.0]))
         nl = int(rng.integers(1, 9))
         ini, mn = int(rng.choice([12, 20, 30, 45])), int(rng.choice([3, 7, 10]))
