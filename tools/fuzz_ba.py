@@ -57,6 +57,23 @@ def main():
         print("cfg %2d cams %3d (fixed %2d) points %4d obs %5d rounds %s robust %d  %s  rel(points) %.1e" % (
             c, nc, nfix, len(w["points"]), len(w["obs"]), rounds, robust, "ok" if ok else "MISMATCH",
             rel(got["points"], ref["points"])), flush=True)
+    # pose-only optimisation: random correspondence counts (incl. < 3 and > the LDS staging budget), outlier rates
+    pbad = 0
+    for c in range(n_cfg):
+        nc, npt = int(rng.integers(4, 12)), int(rng.choice([2, 3, 5, 40, 300, 900, 2500, 6000]))
+        w = synth.make_ba_window(int(rng.integers(1 << 30)), nc, max(npt, 30), outlier_frac=float(rng.choice([0.0, 0.1, 0.3])))
+        cam = int(rng.integers(0, nc))
+        sel = np.nonzero(w["cam_idx"] == cam)[0][:npt]
+        xw, obs, info = w["gt_points"][w["pt_idx"][sel]], w["obs"][sel], w["inv_sigma2"][sel]
+        rp, ro, rn = orc.pose_optimization(w["poses"][cam], xw, obs, info, w["fx"], w["fy"], w["cx"], w["cy"])
+        gp, go, gn = opt.PoseOptimization(w["poses"][cam], xw, obs, info, w["fx"], w["fy"], w["cx"], w["cy"])
+        ok = gn == rn and np.array_equal(go, ro) and np.abs(gp - rp).max() < 1e-5 * max(np.abs(rp).max(), 1.0)
+        pbad += 0 if ok else 1
+        if not ok:
+            print("pose cfg %d n %d: inliers %d/%d flags differ %d dpose %.1e" % (c, len(sel), gn, rn,
+                                                                             int(np.count_nonzero(go != ro)), np.abs(gp - rp).max()))
+    print("FUZZ-POSE %s: %d mismatches in %d problems" % ("FAILED" if pbad else "OK", pbad, n_cfg))
+    bad += pbad
     print("FUZZ-BA %s: %d mismatches in %d configs" % ("FAILED" if bad else "OK", bad, n_cfg))
     return 1 if bad else 0
 
