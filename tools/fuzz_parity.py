@@ -67,6 +67,42 @@ def main():
                 print("MISMATCH match cfg %d win %d ratio %.1f ori %d n1 %d n2 %d" % (c, win, ratio, ori, len(k1), len(k2)))
         print("cfg %2d %4dx%-4d nf %4d scale %.1f nl %d th %2d/%-2d batch %2d kp %s" % (c, w, h, nf, scale, nl, ini, mn, nb,
                                                                                   [len(k) for k, _ in got][:3]), flush=True)
+    # matcher on synthetic features: keypoints of every octave in arbitrary order (not the extractor's level order),
+    # positions partly outside the image bounds, descriptors clustered around a few prototypes (heavy contention)
+    mbad = 0
+    for c in range(n_cfg):
+        n1, n2 = int(rng.integers(1, 2048)), int(rng.integers(1, 2048))
+        nproto, flip = int(rng.integers(1, 60)), int(rng.integers(0, 12))
+        proto = rng.integers(0, 256, (nproto, 32), dtype=np.uint8)
+
+        def mk(n):
+            kp = np.zeros(n, oa.KP_DTYPE)
+            kp["x"], kp["y"] = rng.uniform(-20, 660, n), rng.uniform(-20, 500, n)
+            kp["angle"] = rng.uniform(0, 360, n)
+            kp["octave"] = rng.integers(0, 8, n) if rng.integers(0, 2) else np.sort(rng.integers(0, 8, n))
+            d = proto[rng.integers(0, nproto, n)].copy()
+            nf_ = rng.integers(0, flip + 1, n)
+            for i in range(n):
+                for b_ in rng.integers(0, 256, nf_[i]):
+                    d[i, b_ >> 3] ^= np.uint8(1 << (b_ & 7))
+            return kp, d
+        (k1, d1), (k2, d2) = mk(n1), mk(n2)
+        b = (0.0, 640.0, 0.0, 480.0)
+        win = int(rng.choice([-1, 15, 100, 1000]))
+        ratio, ori = float(rng.choice([0.6, 0.9, 1.0])), bool(rng.integers(0, 2))
+        prev = np.stack([k1["x"], k1["y"]], axis=1).astype(np.float32) + rng.uniform(-8, 8, (n1, 2)).astype(np.float32)
+        on, om12, opm = orc.search_for_initialization(k1, d1, k2, d2, b, prev.copy(), win, ratio, ori)
+        m = oa.ORBmatcher(ratio, ori, max_keypoints=int(rng.choice([2048, 4096])))
+        gp = prev.copy()
+        gn, gm12 = m.SearchForInitialization(oa.FrameFeatures(k1, d1, b), oa.FrameFeatures(k2, d2, b), gp, win)
+        m.close()
+        same = gn == on and np.array_equal(gm12, om12) and np.array_equal(gp, opm)
+        mbad += 0 if same else 1
+        if not same:
+            print("MISMATCH synthetic match cfg %d n1 %d n2 %d protos %d flip %d win %d ratio %.1f ori %d: %d vs %d" % (
+                c, n1, n2, nproto, flip, win, ratio, ori, gn, on))
+    print("FUZZ-MATCH %s: %d mismatches in %d configs" % ("FAILED" if mbad else "OK", mbad, n_cfg))
+    bad += mbad
     print("FUZZ %s: %d mismatches in %d configs" % ("FAILED" if bad else "OK", bad, n_cfg))
     return 1 if bad else 0
 
