@@ -103,6 +103,38 @@ def main():
                 c, n1, n2, nproto, flip, win, ratio, ori, gn, on))
     print("FUZZ-MATCH %s: %d mismatches in %d configs" % ("FAILED" if mbad else "OK", mbad, n_cfg))
     bad += mbad
+    # one handle, a random sequence of calls: frame sizes and batch sizes change from call to call, single frames repeat
+    # (HIP-graph capture, replay and invalidation; staging re-growth; geometry switches; latency / batch quadtree)
+    sbad = 0
+    e = oa.ORBextractor(600, 1.2, 6, 20, 7, max_w=320, max_h=240, max_batch=6)
+    o = orc.OrbOracle(600, 1.2, 6, 20, 7)
+    shapes = [(320, 240), (400, 300), (256, 256), (640, 200), (200, 180)]
+    for c in range(2 * n_cfg):
+        w, h = shapes[int(rng.integers(0, len(shapes)))]
+        nb = int(rng.choice([1, 1, 1, 2, 6, 9]))
+        frames = np.stack([synth.make_frame(int(rng.integers(1 << 30)), w, h, n_shapes=w * h // 90) for _ in range(nb)])
+        if nb == 1:
+            got = [e(frames[0])]
+        elif nb <= 6:
+            got = e.extract_batch(frames)
+        else:  # larger than max_batch: refused, handle stays usable
+            try:
+                e.extract_batch(frames)
+                got = None
+            except oa.OrbError as ex:
+                got = [] if ex.code == oa._lib.ORB_E_CAPACITY else None
+            if got is None:
+                sbad += 1
+                print("MISMATCH sequence call %d: batch %d > max_batch was not refused with ORB_E_CAPACITY" % (c, nb))
+            continue
+        for f, (k, d) in zip(frames, got):
+            ok, od = o.extract(f)
+            if not (np.array_equal(k, ok) and np.array_equal(d, od)):
+                sbad += 1
+                print("MISMATCH sequence call %d: %dx%d batch %d" % (c, w, h, nb))
+    e.close()
+    print("FUZZ-SEQUENCE %s: %d mismatches in %d calls" % ("FAILED" if sbad else "OK", sbad, 2 * n_cfg))
+    bad += sbad
     print("FUZZ %s: %d mismatches in %d configs" % ("FAILED" if bad else "OK", bad, n_cfg))
     return 1 if bad else 0
 
