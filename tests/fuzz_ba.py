@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised BA parity sweep against the CPU oracle: random window sizes, fixed-camera sets, outlier fractions,
 schedules, robust on/off, shuffled camera order; estimates within 1e-5 relative, outlier labels equal.
-Usage: python tools/fuzz_ba.py [n_configs] [seed]"""
+Usage: python tests/fuzz_ba.py [n_configs] [seed]"""
 import os
 import sys
 
@@ -18,9 +18,8 @@ def rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
-def main():
-    n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 24
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
+def run(n_cfg=24, seed=3):
+    rng = np.random.default_rng(seed)
     opt = oa.Optimizer(max_cams=128, max_points=8192, max_obs=80000, max_batch=4)
     bad = 0
     for c in range(n_cfg):
@@ -76,6 +75,10 @@ def main():
     bad += pbad
     print("FUZZ-BA %s: %d mismatches in %d configs" % ("FAILED" if bad else "OK", bad, n_cfg))
     return 1 if bad else 0
+
+
+def main():
+    return run(int(sys.argv[1]) if len(sys.argv) > 1 else 24, int(sys.argv[2]) if len(sys.argv) > 2 else 3)
 
 
 if __name__ == "__main__":

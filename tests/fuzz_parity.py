@@ -2,7 +2,7 @@
 """Randomised parity sweep (not part of the test suite: a few minutes of oracle time): random frame sizes, feature
 budgets, scale factors, pyramid depths and FAST thresholds through the extractor, random window / ratio settings
 through the matcher, single-frame (latency mode) and batched launches, all compared with the CPU oracle bit for bit.
-Usage: python tools/fuzz_parity.py [n_configs] [seed] [wild]"""
+Usage: python tests/fuzz_parity.py [n_configs] [seed] [wild]"""
 import os
 import sys
 
@@ -15,10 +15,8 @@ from oracle import oracle as orc  # noqa: E402
 from orbslam_in_practice_amd import synth  # noqa: E402
 
 
-def main():
-    n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-    wild = len(sys.argv) > 3 and sys.argv[3] == "wild"
+def run(n_cfg=30, seed=1, wild=False):
+    rng = np.random.default_rng(seed)
     bad = 0
     for c in range(n_cfg):
         if wild:  # extreme shapes and budgets
@@ -137,6 +135,11 @@ def main():
     bad += sbad
     print("FUZZ %s: %d mismatches in %d configs" % ("FAILED" if bad else "OK", bad, n_cfg))
     return 1 if bad else 0
+
+
+def main():
+    return run(int(sys.argv[1]) if len(sys.argv) > 1 else 30, int(sys.argv[2]) if len(sys.argv) > 2 else 1,
+               len(sys.argv) > 3 and sys.argv[3] == "wild")
 
 
 if __name__ == "__main__":

@@ -1,0 +1,27 @@
+"""A short run of the randomised parity sweeps (tests/fuzz_parity.py, tests/fuzz_ba.py) inside the GPU suite: random
+frame shapes / budgets / pyramid settings, matcher settings, stateful call sequences on one handle, BA windows and pose
+problems, every result compared with the CPU oracle.  `python tests/fuzz_parity.py N SEED [wild]` and
+`python tests/fuzz_ba.py N SEED` run the same code with more configurations."""
+import importlib.util
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load(name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tests", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("seed,wild", [(20261, False), (20262, True)])
+def test_front_end_fuzz(seed, wild):
+    assert _load("fuzz_parity").run(6, seed, wild) == 0
+
+
+def test_ba_fuzz():
+    assert _load("fuzz_ba").run(8, 20263) == 0
