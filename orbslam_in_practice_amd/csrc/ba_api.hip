@@ -668,9 +668,18 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
             for (int i = 0; i < 36; i++) acc[i] = 0.0;
             if (bk < w.nnzb) {
                 const int k0 = I[w.con_start + bk], k1 = I[w.con_start + bk + 1];
-                for (int k = k0 + l16; k < k1; k += 16) {
-                    const double2 *Y1 = (const double2 *)(D + w.Y + (int64_t)I[w.con_e1 + k] * 18); /* 144-B records */
-                    const double2 *W2 = (const double2 *)(D + w.W + (int64_t)I[w.con_e2 + k] * 18);
+                /* the edge ids of the NEXT contribution are fetched before the 36 operand loads of the current one,
+                   so that the index round trip hides behind the data round trip instead of preceding it */
+                int kq = k0 + l16;
+                int e1n = kq < k1 ? I[w.con_e1 + kq] : 0, e2n = kq < k1 ? I[w.con_e2 + kq] : 0;
+                for (int k = kq; k < k1; k += 16) {
+                    const int e1 = e1n, e2 = e2n;
+                    if (k + 16 < k1) {
+                        e1n = I[w.con_e1 + k + 16];
+                        e2n = I[w.con_e2 + k + 16];
+                    }
+                    const double2 *Y1 = (const double2 *)(D + w.Y + (int64_t)e1 * 18); /* 144-B records */
+                    const double2 *W2 = (const double2 *)(D + w.W + (int64_t)e2 * 18);
                     double y[18], ww[18];
 #pragma unroll
                     for (int i = 0; i < 9; i++) {
