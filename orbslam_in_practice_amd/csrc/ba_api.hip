@@ -57,6 +57,7 @@ static OrbErrSlot b_err; /* forwards to orb_last_error() */
 /* per-window descriptor: element offsets into the batch buffers */
 struct BAWin {
     int Nc, Np, E, Ncf, nnzb, nub; /* nub: blocks on or above the diagonal */
+    int ch_pm;                     /* rows of the Cholesky LDS panel: 16 x the widest envelope column (tile rows below a diagonal tile) */
     double fx, fy, cx, cy, delta, chi2_thr;
     /* doubles */
     int64_t poses, poses_t, pts, pts_t, obs, info, err, err_t, W, Y, Hpp, bp, Hll, bl, Dinv, S, g, Minv, x, xl, st;
@@ -299,8 +300,8 @@ __device__ __noinline__ bool ba_chol_solve(const BAWin &w, double *D, const int3
     const int np = (n + 15) & ~15, nb = np >> 4;
     double *A = D + w.A;
     double *Li = D + w.Linv;
-    double *P = dyn;                        /* panel: np x CH_LD            */
-    double *sd = P + (size_t)np * CH_LD;    /* diagonal block, 16 x CH_LD   */
+    double *P = dyn;                        /* panel: ch_pm x CH_LD (only the tile rows that reach a column) */
+    double *sd = P + (size_t)w.ch_pm * CH_LD; /* diagonal block, 16 x CH_LD   */
     double *sl = sd + 16 * CH_LD;           /* its inverse, 16 x CH_LD      */
     double *z = sl + 16 * CH_LD;            /* right-hand side / solution   */
     /* ---- assemble the dense matrix from the block-sparse S ---- */
@@ -763,7 +764,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
         /* linear solver of the reduced camera system: dense blocked Cholesky (MFMA f64) when its LDS panel fits,
            PCG otherwise / on request */
         const int np_ = (n + 15) & ~15;
-        const bool use_chol = solver == 1 && n > 0 && (np_ * CH_LD + 2 * 16 * CH_LD + np_) <= dyn_doubles;
+        const bool use_chol = solver == 1 && n > 0 && (w.ch_pm * CH_LD + 2 * 16 * CH_LD + np_) <= dyn_doubles;
         if (use_chol) {
             BA_STAMP(5)
             ok2 = ba_chol_solve(w, D, I, n, ba_dyn, s);
@@ -1343,6 +1344,9 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hD, size_t &sc
             while (l + 1 < nbt && first[l + 1] <= k) l++;
             last[k] = l;
         }
+        int maxm = 1;
+        for (int k = 0; k < nbt; k++) maxm = std::max(maxm, last[k] - k);
+        w.ch_pm = maxm * 16;
         w.ch_first = allocI(std::max(nbt, 1));
         w.ch_last = allocI(std::max(nbt, 1));
         for (int t = 0; t < nbt; t++) {
@@ -1484,9 +1488,13 @@ extern "C" int ba_solve_batch(BASolver *s, const BAProblem *probs, BAResult *res
     /* dynamic LDS of the Cholesky solver: panel + two 16x16 blocks + rhs, for the largest window of the batch */
     int dyn_doubles = 0;
     if (s->solver == 1) {
-        const int npmax = (maxn + 15) & ~15;
-        const size_t need = (size_t)npmax * 17 + 2 * 16 * 17 + npmax;
-        if (need * 8 <= 128 * 1024) dyn_doubles = (int)need; /* larger systems fall back to PCG inside the kernel */
+        /* per window: envelope-sized panel + two 16x16 blocks + rhs; windows whose need exceeds 128 KB (a wide
+           envelope AND many cameras) fall back to PCG inside the kernel */
+        for (int i = 0; i < nwin; i++) {
+            const size_t npw = ((size_t)wins[i].Ncf * 6 + 15) & ~(size_t)15;
+            const size_t need = (size_t)wins[i].ch_pm * 17 + 2 * 16 * 17 + npw;
+            if (need * 8 <= 128 * 1024) dyn_doubles = std::max(dyn_doubles, (int)need);
+        }
         static PerDeviceLdsLimit lim;
         if (lim.raise((size_t)dyn_doubles * 8))
             BCHK(hipFuncSetAttribute((const void *)k_ba_iteration, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -185,3 +185,21 @@ def test_ba_shuffled_camera_order(opt, oracle, nc, npt, seed):
     assert _rel(got["points"], ref["points"]) < REL
     assert _rel(got["poses"][:, 4:], ref["poses"][:, 4:]) < REL
     assert abs(got["chi2_final"] - ref["chi2_final"]) <= 1e-6 * ref["chi2_final"]
+
+
+def test_ba_many_cameras_envelope_panel(oracle):
+    """160 free cameras: the dense reduced system is 960 x 960, its full-height LDS panel (130 KB) would not fit, the
+    envelope-sized one (a band of a few tiles for a chain-like window) does -- the blocked Cholesky still runs and
+    still agrees with the oracle"""
+    import orbslam_in_practice_amd as oa
+    from orbslam_in_practice_amd import synth
+    w = synth.make_ba_window(4242, 162, 4000)
+    w["fixed"][:2] = 1
+    o = oa.Optimizer(max_cams=170, max_points=4096, max_obs=40000, max_batch=1)
+    ref = oracle.ba_solve(w, rounds=(5, 5))
+    got = o.solve_batch([w], (5, 5))[0]
+    assert got["iterations"] == ref["iterations"]
+    assert np.array_equal(got["outlier"], ref["outlier"])
+    assert _rel(got["points"], ref["points"]) < REL
+    assert _rel(got["poses"][:, 4:], ref["poses"][:, 4:]) < REL
+    o.close()
