@@ -527,14 +527,34 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
     for (int p = tid; p < w.Np; p += BA_T) {
         double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
         const int e0 = I[w.pt_start + p], e1 = I[w.pt_start + p + 1];
+        /* software pipeline over the point's edges: flag, camera id, residual and information of the NEXT edge are
+           fetched while the current one waits for its pose (one dependent round trip per edge instead of three) */
+        uint8_t fn = 0;
+        int cn = 0;
+        double er0n = 0, er1n = 0, infon = 0;
+        if (e0 < e1) {
+            fn = B[w.flags + e0];
+            cn = I[w.cam + e0];
+            er0n = D[w.err + (int64_t)e0 * 2];
+            er1n = D[w.err + (int64_t)e0 * 2 + 1];
+            infon = D[w.info + e0];
+        }
         for (int e = e0; e < e1; e++) {
-            const uint8_t f = B[w.flags + e];
+            const uint8_t f = fn;
+            const int c = cn;
+            const double er0 = er0n, er1 = er1n, info = infon;
+            if (e + 1 < e1) {
+                fn = B[w.flags + e + 1];
+                cn = I[w.cam + e + 1];
+                er0n = D[w.err + (int64_t)(e + 1) * 2];
+                er1n = D[w.err + (int64_t)(e + 1) * 2 + 1];
+                infon = D[w.info + e + 1];
+            }
             double *We = D + w.W + (int64_t)e * 18;
             if (!(f & 1)) {
                 for (int i = 0; i < 18; i++) We[i] = 0.0;
                 continue;
             }
-            const int c = I[w.cam + e];
             const double *pose = D + w.poses + (int64_t)c * 7;
             const double *X = D + w.pts + (int64_t)p * 3;
             double R[9], pc[3];
@@ -544,8 +564,6 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
             pc[2] = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + pose[6];
             double Ji[6], Jj[12];
             jacobians(pose, pc, w.fx, w.fy, Ji, Jj);
-            const double er0 = D[w.err + (int64_t)e * 2], er1 = D[w.err + (int64_t)e * 2 + 1];
-            const double info = D[w.info + e];
             double wgt = info, r0 = -info * er0, r1 = -info * er1;
             if (f & 2) {
                 const double rw = huber_w((er0 * er0 + er1 * er1) * info, w.delta);
