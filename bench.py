@@ -1,20 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py -- hot-path throughput of the MI355X ORB front-end (BASELINE.json configs[1]).
+"""bench.py -- hot-path throughput of the MI355X ORB front-end and local-BA back-end (BASELINE.json configs[1] + the
+north_star BA target).
 
-One "step" = one pass of the hot path over one batch: ORB extraction (8-level pyramid, FAST cells,
-quadtree, blur, rBRIEF) of B synthetic 640x480 frames per GPU + brute-force Hamming matching of the
-B consecutive frame pairs (k, k+1).  Inputs are resident in HBM before the timed region starts;
-outputs stay in HBM.  With N > 1 GPUs every rank processes its own B frames (weak scaling) and the
-per-frame feature slabs are exchanged with ONE round of RCCL all-gathers so that the last local frame
-is matched against the first frame of the next rank.
+One "step" = `--batches-per-step` (default 8) passes of the front-end over a batch of B = 512 synthetic 640x480 frames
+per GPU: ORB extraction (8-level pyramid, FAST cells, quadtree, blur, rBRIEF) + brute-force Hamming matching of the B
+consecutive frame pairs (k, k+1) -- 4096 frames per GPU per step, so that the timed region of the default run is
+well over half a second.  Inputs are resident in HBM before the timed region starts; outputs stay in HBM.  With N > 1
+GPUs every rank processes its own frames (weak scaling) and the one exchange step of the path is an RCCL all-gather of
+the first frame slab of every rank (the last local frame is matched against the first frame of the next rank).
+
+The second half of BASELINE's metric, local-BA windows/s (100 keyframes x 5000 points, 5+10 LM iterations), is
+measured after the front-end on every rank -- windows are independent units sharded by rank, no collective -- and
+reported under `local_ba` with its own roofline, CPU baseline and the one-window-in-flight latency.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line (see the driver contract) with `roofline` (dominant stage, live HIP-event
-timing) and, at N == 1, `cpu_baseline` (the CPU oracle -- a port of the reference path -- timed on a
-bounded sample on this box's host cores).
+Rank 0 prints ONE JSON line (driver contract) with `roofline` (dominant kernel, HIP-event durations measured in a
+separate pass after the timed region) and, at N == 1, `cpu_baseline` (the CPU oracle -- a port of the reference path --
+timed on a bounded sample on this box's host cores).
 """
 import argparse
 import ctypes as C
@@ -31,6 +36,7 @@ sys.path.insert(0, ROOT)
 W, H = 640, 480
 NFEATURES, SCALE, NLEVELS, INI_TH, MIN_TH = 1000, 1.2, 8, 20, 7
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+VALU_PEAK_GINST = 1024 * 1.2  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles at 2.4 GHz
 
 
 def algorithmic_bytes_per_frame(level_sizes, n_kp):
@@ -90,34 +96,100 @@ def cpu_baseline(n_frames):
     return one, allc
 
 
-def ba_throughput(device, n_windows):
-    """second half of BASELINE.json's metric: local-BA windows/s at the north_star target size
-    (100 KFs x 5000 points, 5+10 LM iterations), a batch of independent windows on this GPU"""
+def ba_algorithmic_bytes(w, iterations, lin_solves):
+    """SURVEY.md 8(d), f64: bytes one window moves over its whole solve -- linearise/build once per LM iteration;
+    Schur complement, back-substitution and update + re-evaluation once per linear solve (LM trial).  No PCG term:
+    the reduced system is solved by the in-kernel Cholesky, whose matrix stays in L2.  Schur output = the non-zero
+    6x6 blocks of S (co-observing free camera pairs), not the dense Nc^2 bound."""
+    Nc, Np, E = len(w["poses"]), len(w["points"]), len(w["obs"])
+    vis = np.zeros((Np, Nc), np.float32)
+    vis[w["pt_idx"], w["cam_idx"]] = 1.0
+    vis[:, w["fixed"] != 0] = 0.0
+    nnzb = int(np.count_nonzero(vis.T @ vis))
+    build = (E * 32 + Nc * 56 + Np * 24) + (Nc * 288 + Np * 72 + E * 144 + Nc * 48 + Np * 24)
+    per_solve = (E * 144 + Np * 72) + nnzb * 288 + (E * 144 + Np * 120 + Nc * 48) + (E * 32 + 2 * (Nc * 56 + Np * 24))
+    return iterations * build + lin_solves * per_solve
+
+
+def ba_bench(dev_index, rank, world, n_windows, nc, npt, reps, barrier, max_over_ranks, with_cpu):
+    """second half of BASELINE.json's metric: local-BA windows/s at the north_star target size (100 KFs x 5000 points,
+    5+10 LM iterations).  Windows are independent units: rank r solves its own n_windows per batch (weak scaling, no
+    collective); 32 distinct windows per rank.  `value` is the steady state of a stream of batches through
+    ba_submit_batch / ba_wait (host staging and PCIe of batch k+1 under the kernels of batch k), host side included."""
     import orbslam_in_practice_amd as oa
     from orbslam_in_practice_amd import synth
-    uniq = [synth.make_ba_window(900 + i, 100, 5000) for i in range(4)]
-    wins = [uniq[i % 4] for i in range(n_windows)]
+    n_uniq = min(32, n_windows)
+    uniq = [synth.make_ba_window(900 + 64 * rank + i, nc, npt) for i in range(n_uniq)]
+    wins = [uniq[i % n_uniq] for i in range(n_windows)]
     E = max(len(w["obs"]) for w in uniq)
-    opt = oa.Optimizer(max_cams=100, max_points=5000, max_obs=E, max_batch=n_windows, device=device)
+    opt = oa.Optimizer(max_cams=nc, max_points=npt, max_obs=E, max_batch=n_windows, device=dev_index)
     opt.solve_batch(wins, (5, 10))  # warm-up at full size: device / pinned buffers and staging vectors reach steady state
-    reps = 2
+    opt.submit_batch(wins, (5, 10))
+    opt.submit_batch(wins, (5, 10))
+    opt.wait()
+    opt.wait()                      # ... for both job slots
+    barrier()
     t0 = time.perf_counter()
-    for _ in range(reps):
-        res = opt.solve_batch(wins, (5, 10))
-    dt = (time.perf_counter() - t0) / reps
-    opt.close()
-    # the CPU oracle (dense Cholesky on the Schur complement, g2o semantics) on a bounded sample of the same windows
-    from oracle import oracle as orc
+    opt.submit_batch(wins, (5, 10))
+    for _ in range(reps - 1):
+        opt.submit_batch(wins, (5, 10))
+        res = opt.wait()
+    res = opt.wait()
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    # one synchronous call, HIP events around every k_ba_iteration launch: the roofline of the BA kernel
+    opt.set_profiling(True)
     t1 = time.perf_counter()
-    for w in uniq:
-        orc.ba_solve(w, rounds=(5, 10))
-    cpu_dt = (time.perf_counter() - t1) / len(uniq)
-    return {"value": round(n_windows / dt, 2), "unit": "windows/s", "dtype": "f64",
-            "cpu_baseline": {"value": round(1.0 / cpu_dt, 3), "unit": "windows/s", "cores": 1, "kind": "port",
-                             "sample": "%d of the same windows through oracle/ba_oracle.cpp, %.1f s" % (len(uniq), cpu_dt * len(uniq))},
-            "workload": "local BA, %d windows of 100 KFs x 5000 points (E~%d), 5+10 LM iterations, host staging "
-                        "included, mean of %d calls" % (n_windows, E, reps),
-            "chi2_ratio": round(float(np.mean([r["chi2_final"] / r["chi2_initial"] for r in res])), 5)}
+    res = opt.solve_batch(wins, (5, 10))
+    sync_dt = time.perf_counter() - t1
+    iter_ms, launches, team = opt.iteration_ms()
+    opt.set_profiling(False)
+    by_uniq = [ba_algorithmic_bytes(uniq[i], res[i]["iterations"], res[i]["lin_solves"]) for i in range(n_uniq)]
+    total_bytes = sum(by_uniq[i % n_uniq] for i in range(n_windows))
+    a = total_bytes / max(launches, 1) / (iter_ms * 1e-3) / 1e9 if iter_ms > 0 else 0.0
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if "ba_iteration" in tj:
+            traffic = int(tj["ba_iteration"] * n_windows / float(tj.get("_ba_batch", n_windows)))
+    except Exception:
+        pass
+    roof = {"bound": "hbm", "kernel": "k_ba_iteration", "achieved": round(a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(a / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "algorithmic_bytes_per_launch": int(total_bytes / max(launches, 1)), "windows_per_launch": n_windows,
+            "launches": launches, "avg_launch_ms": round(iter_ms, 4), "workgroups_per_window": team,
+            "lin_solves_per_window": round(float(np.mean([r["lin_solves"] for r in res])), 2)}
+    # ONE window in flight: the LocalMapping call pattern (one local BA per new keyframe)
+    one = opt.solve_batch([uniq[0]], (5, 10))
+    t2 = time.perf_counter()
+    nrep1 = 5
+    for i in range(nrep1):
+        one = opt.solve_batch([uniq[i % n_uniq]], (5, 10))
+    single_ms = (time.perf_counter() - t2) / nrep1 * 1e3
+    opt.set_profiling(True)
+    opt.solve_batch([uniq[0]], (5, 10))
+    s_ms, s_launches, s_team = opt.iteration_ms()
+    opt.close()
+    out = {"value": round(world * n_windows * reps / dt, 2), "unit": "windows/s", "dtype": "f64", "n_gpus": world,
+           "scaling": "weak", "roofline": roof,
+           "workload": "local BA, %d windows per GPU per batch (%d distinct) of %d KFs x %d points (E~%d), 5+10 LM "
+                       "iterations, %d batches through ba_submit_batch/ba_wait, host staging + PCIe included"
+                       % (n_windows, n_uniq, nc, npt, E, reps),
+           "sync_call_windows_per_s": round(n_windows / sync_dt, 2),
+           "single_window_ms": round(single_ms, 3), "single_window_windows_per_s": round(1e3 / single_ms, 2),
+           "single_window": {"workgroups_per_window": s_team, "avg_iteration_launch_ms": round(s_ms, 4), "launches": s_launches},
+           "chi2_ratio": round(float(np.mean([r["chi2_final"] / r["chi2_initial"] for r in res])), 5)}
+    if with_cpu:
+        # the CPU oracle (dense Cholesky on the Schur complement, g2o semantics) on a bounded sample of the same windows
+        from oracle import oracle as orc
+        ncpu = min(8, n_uniq)
+        t3 = time.perf_counter()
+        for w in uniq[:ncpu]:
+            orc.ba_solve(w, rounds=(5, 10))
+        cpu_dt = (time.perf_counter() - t3) / ncpu
+        out["cpu_baseline"] = {"value": round(1.0 / cpu_dt, 3), "unit": "windows/s", "cores": 1, "kind": "port",
+                               "sample": "%d of the same windows through oracle/ba_oracle.cpp, %.1f s" % (ncpu, cpu_dt * ncpu)}
+    return out
 
 
 def main():
@@ -126,14 +198,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=512, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=512, help="frames per GPU per launch group")
+    ap.add_argument("--batches-per-step", type=int, default=8, help="batches of --batch frames one step processes")
     ap.add_argument("--cpu-frames", type=int, default=200, help="CPU baseline sample size (0 = skip); 200 frames = ~9 s on one core")
     ap.add_argument("--size", default="640x480", help="frame size WxH (configs[1] = 640x480; 1280x720 = configs[3] shape)")
     ap.add_argument("--window", type=int, default=-1, help="match window (-1 = brute force; 100 = the reference's "
                     "SearchForInitialization call, src/Tracking.cpp:189)")
     ap.add_argument("--nfeatures", type=int, default=NFEATURES)
     ap.add_argument("--split", type=int, default=2, help="1..4 launch lanes: equal parts of a batch on separate stream pairs")
-    ap.add_argument("--ba-windows", type=int, default=256, help="windows in the local-BA side measurement (0 = skip)")
+    ap.add_argument("--ba-windows", type=int, default=256, help="local-BA windows per GPU per batch (0 = skip)")
+    ap.add_argument("--ba-size", default="100x5000", help="keyframes x points of a window (configs[2] = 50x2000)")
+    ap.add_argument("--ba-reps", type=int, default=6, help="batches in the timed BA stream")
     args = ap.parse_args()
     W, H = (int(v) for v in args.size.lower().split("x"))
     NFEATURES = args.nfeatures
@@ -162,96 +237,77 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    def all_gather_flat(out, inp):
-        if rehearse:  # gloo: list form
-            parts = list(out.view(world, -1).unbind(0))
-            dist.all_gather(parts, inp.view(-1))
-        else:
-            dist.all_gather_into_tensor(out.view(-1), inp.view(-1))
-
     import orbslam_in_practice_amd as oa
-    from orbslam_in_practice_amd import synth
+    from orbslam_in_practice_amd import shard, synth
 
     B = args.batch
-    ext = oa.ORBextractor(NFEATURES, SCALE, NLEVELS, INI_TH, MIN_TH, max_w=W, max_h=H, max_batch=B,
-                          device=local_rank)
-    cap = ext.cap
-    matcher = oa.ORBmatcher(0.9, True, max_keypoints=cap, max_pairs=B, device=local_rank)
-    # a second extractor/matcher pair lets the two HALVES of a step's batch run on their own streams: the
-    # latency-bound stages of one half (quadtree, match resolution) then overlap the throughput-bound stages of
-    # the other (pyramid, FAST, blur)
+    S = max(1, args.batches_per_step)
     nsplit = max(1, min(args.split, 4))
-    more_ext = [oa.ORBextractor(NFEATURES, SCALE, NLEVELS, INI_TH, MIN_TH, max_w=W, max_h=H, max_batch=B, device=local_rank)
-                for _ in range(nsplit - 1)]
-    more_match = [oa.ORBmatcher(0.9, True, max_keypoints=cap, max_pairs=B, device=local_rank) for _ in range(nsplit - 1)]
+    # one extractor/matcher pair per launch lane: the lanes of a batch run on their own streams, so the latency-bound
+    # stages of one (quadtree, match resolution) overlap the throughput-bound stages of the other (pyramid, FAST, blur)
+    exts = [oa.ORBextractor(NFEATURES, SCALE, NLEVELS, INI_TH, MIN_TH, max_w=W, max_h=H, max_batch=B, device=local_rank)
+            for _ in range(nsplit)]
+    ext = exts[0]
+    cap = ext.cap
+    matchers = [oa.ORBmatcher(0.9, True, max_keypoints=cap, max_pairs=B, device=local_rank) for _ in range(nsplit)]
+    matcher = matchers[0]
 
+    # S distinct batches per step, all resident in HBM: batch 0 is a synthetic stream of B frames, batch j the same
+    # stream translated by (7j, 13j) pixels (circularly) -- different pixels under every FAST cell and pyramid tap
     frames = synth.make_stream(1000 + rank, B, W, H)
-    d_imgs = torch.from_numpy(frames).to(dev)
-    nG = world * B  # frames visible to the matcher after the exchange
-    lo = rank * B
-    from orbslam_in_practice_amd import shard
-    pa_h, pb_h = shard.stream_pairs(rank, world, B)  # (k, k+1) in the global stream; the last one wraps
+    d_base = torch.from_numpy(frames).to(dev)
+    d_imgs = [d_base] + [torch.roll(d_base, shifts=(7 * j, 13 * j), dims=(1, 2)).contiguous() for j in range(1, S)]
+    rows = shard.halo_rows(world, B)
+    pa_h, pb_h = shard.halo_pairs(rank, world, B)  # (k, k+1) in LOCAL slab rows; the last one points into the halo
     pa = torch.from_numpy(pa_h).to(dev)
     pb = torch.from_numpy(pb_h).to(dev)
     bounds = (0.0, float(W), 0.0, float(H))
+    exchange = shard.HaloExchange(world, B)
 
-    # Two HIP streams, double-buffered feature slabs: the (latency-bound) match of batch k runs on stream B
+    # Two stream pairs per lane, double-buffered feature slabs: the (latency-bound) match of batch k runs on stream B
     # while stream A already extracts batch k+1.
     class Slab:
         def __init__(self):
-            self.kps = torch.zeros((nG, cap, 28), dtype=torch.uint8, device=dev)
-            self.desc = torch.zeros((nG, cap, 32), dtype=torch.uint8, device=dev)
-            self.cnt = torch.zeros((nG,), dtype=torch.int32, device=dev)
-            if world > 1:  # separate send buffers: the all-gather never aliases its own output
-                self.k_loc = torch.zeros((B, cap, 28), dtype=torch.uint8, device=dev)
-                self.d_loc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
-                self.c_loc = torch.zeros((B,), dtype=torch.int32, device=dev)
-            else:
-                self.k_loc, self.d_loc, self.c_loc = self.kps, self.desc, self.cnt
+            self.kps = torch.zeros((rows, cap, 28), dtype=torch.uint8, device=dev)
+            self.desc = torch.zeros((rows, cap, 32), dtype=torch.uint8, device=dev)
+            self.cnt = torch.zeros((rows,), dtype=torch.int32, device=dev)
             self.m12 = torch.full((B, cap), -1, dtype=torch.int32, device=dev)
             self.nm = torch.zeros((B,), dtype=torch.int32, device=dev)
-            self.extracted = torch.cuda.Event()
-            self.matched = torch.cuda.Event()
+            self.extracted = [torch.cuda.Event() for _ in range(nsplit)]
+            self.matched = [torch.cuda.Event() for _ in range(nsplit)]
             self.gathered = torch.cuda.Event()
 
     slabs = [Slab(), Slab()]
-    exts = [ext] + more_ext
-    matchers = [matcher] + more_match
     sAs = [torch.cuda.Stream(device=dev) for _ in range(nsplit)]
     sBs = [torch.cuda.Stream(device=dev) for _ in range(nsplit)]
-    for sl in slabs:
-        sl.extracted = [torch.cuda.Event() for _ in range(nsplit)]
-        sl.matched = [torch.cuda.Event() for _ in range(nsplit)]
     Bh = B // nsplit  # frames per launch
     assert Bh * nsplit == B
-    step_no = [0]
+    batch_no = [0]
 
-    def step():
-        sl = slabs[step_no[0] & 1]
-        step_no[0] += 1
+    def one_batch(d_in):
+        sl = slabs[batch_no[0] & 1]
+        batch_no[0] += 1
         for hh in range(nsplit):
             sA = sAs[hh]
             with torch.cuda.stream(sA):
                 for ev in sl.matched:
                     sA.wait_event(ev)  # the matches that last read this slab have finished
                 f0 = hh * Bh
-                exts[hh].extract_batch_device(d_imgs.data_ptr() + f0 * W * H, Bh, W, H, W, W * H,
-                                              sl.k_loc.data_ptr() + f0 * cap * 28, sl.d_loc.data_ptr() + f0 * cap * 32, cap,
-                                              sl.c_loc.data_ptr() + f0 * 4, C.c_void_p(sA.cuda_stream))
+                exts[hh].extract_batch_device(d_in.data_ptr() + f0 * W * H, Bh, W, H, W, W * H,
+                                              sl.kps.data_ptr() + f0 * cap * 28, sl.desc.data_ptr() + f0 * cap * 32, cap,
+                                              sl.cnt.data_ptr() + f0 * 4, C.c_void_p(sA.cuda_stream))
                 sl.extracted[hh].record(sA)
         for hh in range(nsplit):
             sB = sBs[hh]
             with torch.cuda.stream(sB):
                 for ev in sl.extracted:
-                    sB.wait_event(ev)  # pair (k, k+1) may straddle the halves
+                    sB.wait_event(ev)  # pair (k, k+1) may straddle the lanes
                 if world > 1:
-                    # the one exchange step of the path: fixed-capacity feature slabs over xGMI (RCCL all-gather),
-                    # once per step for the rank's whole block.  It lives on lane 0's MATCH stream, so the next
-                    # batch's extraction (streams A) overlaps it; the other lane's match waits for its event.
+                    # the one exchange step of the path: the first frame slab of every rank over xGMI (RCCL
+                    # all-gather, 3 x world x ~20 KB), on lane 0's MATCH stream, so the next batch's extraction
+                    # (streams A) overlaps it; the other lanes' matches wait for its event.
                     if hh == 0:
-                        all_gather_flat(sl.kps, sl.k_loc)
-                        all_gather_flat(sl.desc, sl.d_loc)
-                        all_gather_flat(sl.cnt, sl.c_loc)
+                        exchange(sl.kps, sl.desc, sl.cnt)
                         sl.gathered.record(sB)
                     else:
                         sB.wait_event(sl.gathered)
@@ -262,45 +318,61 @@ def main():
                                                 C.c_void_p(sB.cuda_stream))
                 sl.matched[hh].record(sB)
 
+    def step():
+        for j in range(S):
+            one_batch(d_imgs[j])
+
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
 
-    L = oa._lib.lib()
-    if True:
-        for _ in range(args.warmup):
-            step()
-        barrier()
-        oa._lib.check(L.orb_set_profiling(ext._h, 1))
-        oa._lib.check(L.orb_matcher_set_profiling(matcher._m, 1))
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        barrier()
-        elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
 
-    # live per-stage durations (HIP events on the launch stream, averaged over the timed steps)
+    L = oa._lib.lib()
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+
+    # per-stage durations: a SEPARATE pass after the timed region, HIP events on the launch streams between the stages
+    oa._lib.check(L.orb_set_profiling(ext._h, 1))
+    oa._lib.check(L.orb_matcher_set_profiling(matcher._m, 1))
+    for _ in range(3):
+        step()
+    barrier()
     ms5 = (C.c_float * 5)()
     oa._lib.check(L.orb_get_stage_ms(ext._h, ms5))
     mm = (C.c_float * 2)()
     oa._lib.check(L.orb_matcher_get_stage_ms(matcher._m, mm))
+    oa._lib.check(L.orb_set_profiling(ext._h, 0))
+    oa._lib.check(L.orb_matcher_set_profiling(matcher._m, 0))
     stage_ms = dict(zip(["pyramid", "fast", "quadtree", "blur", "describe"], [float(v) for v in ms5]))
     stage_ms["match_knn"], stage_ms["match_resolve"] = float(mm[0]), float(mm[1])
-    counts = slabs[0].c_loc.cpu().numpy()
+    counts = slabs[0].cnt[:B].cpu().numpy()
     nmatch = slabs[0].nm.cpu().numpy()
     n_kp = float(counts.mean())
 
+    local_ba = None
+    if args.ba_windows > 0:
+        nc, npt = (int(v) for v in args.ba_size.lower().split("x"))
+        local_ba = ba_bench(local_rank, rank, world, args.ba_windows, nc, npt, max(2, args.ba_reps), barrier, max_over_ranks,
+                            with_cpu=(rank == 0 and world == 1))
+
     if rank == 0:
-        fps = world * B * args.steps / elapsed
+        fps = world * B * S * args.steps / elapsed
         ab = algorithmic_bytes_per_frame(ext.level_sizes(W, H), n_kp)
-        # the dominant KERNEL: the single-launch stage with the longest average duration in the timed region
-        # ("pyramid" is eight launches -- level-0 copy + seven resizes -- and is listed under roofline_stages only)
+        # the dominant KERNEL: the single-launch stage with the longest average duration
+        # ("pyramid" is several launches -- level-0 copy + resizes -- and is listed under roofline_stages only)
         timed = {k: v for k, v in stage_ms.items() if ab.get(k, 0) > 0 and k in SINGLE_KERNEL_STAGES}
         dom = max(timed, key=timed.get)
         tj = {}
@@ -316,25 +388,34 @@ def main():
             # per-frame traffic is batch independent
             a = ab[k] * Bh / (stage_ms[k] * 1e-3) / 1e9
             t = int(tj[k] * Bh / float(tj.get("_batch", Bh))) if k in tj else None
-            return {"bound": "hbm", "kernel": k, "achieved": round(a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(a / HBM_PEAK_GBS, 5), "traffic": t, "algorithmic_bytes_per_launch": int(ab[k] * Bh),
-                    "frames_per_launch": Bh, "avg_launch_ms": round(stage_ms[k], 4)}
-        pipe_bytes = sum(ab.values()) * world * B * args.steps
+            r = {"bound": "hbm", "kernel": k, "achieved": round(a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(a / HBM_PEAK_GBS, 5), "traffic": t, "algorithmic_bytes_per_launch": int(ab[k] * Bh),
+                 "frames_per_launch": Bh, "avg_launch_ms": round(stage_ms[k], 4)}
+            vk = "valu_insts_" + k  # SQ_INSTS_VALU per launch (PMC pass, profiles/traffic.json): issue-rate view of a VALU-bound kernel
+            if vk in tj:
+                ginst = tj[vk] * Bh / float(tj.get("_batch", Bh)) / 1e9
+                r["valu"] = {"insts_per_launch": int(ginst * 1e9), "achieved_ginst_s": round(ginst / (stage_ms[k] * 1e-3), 1),
+                             "peak_ginst_s": VALU_PEAK_GINST, "frac": round(ginst / (stage_ms[k] * 1e-3) / VALU_PEAK_GINST, 4)}
+            return r
+        pipe_bytes = sum(ab.values()) * world * B * S * args.steps
         pipe = pipe_bytes / elapsed / 1e9
         out = {
-            "metric": "frames/s ORB extract+match @%dx%d" % (W, H), "value": round(fps, 2), "unit": "frames/s",
+            "metric": "frames/s ORB extract+match @%dx%d (local-BA windows/s under local_ba)" % (W, H),
+            "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "rehearsal": rehearse,
+            "rehearsal": rehearse, "timed_region_s": round(elapsed, 4),
             "config": {"workload": "%s: ORB extract (8 levels, %d features, FAST 20/7) + %s match of consecutive "
                                    "frames, %dx%d stream" % ("configs[1]" if (W, H, args.window) == (640, 480, -1) else
                                                              "variant", NFEATURES,
                                                              "brute-force Hamming" if args.window < 0 else
                                                              "SearchForInitialization(window=%d)" % args.window, W, H),
-                       "frames_per_gpu_per_step": B, "pairs_per_gpu_per_step": B, "launch_lanes": nsplit,
+                       "frames_per_gpu_per_step": B * S, "pairs_per_gpu_per_step": B * S, "frames_per_batch": B,
+                       "batches_per_step": S, "launch_lanes": nsplit,
                        "keypoints_per_frame": round(n_kp, 1), "matches_per_pair": round(float(nmatch.mean()), 1),
-                       "exchange": "rccl all_gather of kp/desc/count slabs" if world > 1 else "none"},
+                       "exchange": ("rccl all_gather of the first frame slab of every rank (%d B per rank per batch)"
+                                    % exchange.bytes_per_rank(cap)) if world > 1 else "none"},
             "roofline": stage_roofline(dom),
             "roofline_stages": [stage_roofline(k) for k in stage_ms if ab.get(k, 0) > 0],
             "roofline_pipeline": {"bound": "hbm", "achieved": round(pipe, 2), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
@@ -344,8 +425,8 @@ def main():
         }
         if world == 1 and args.cpu_frames > 0:
             out["cpu_baseline"], out["cpu_baseline_all_cores"] = cpu_baseline(args.cpu_frames)
-        if world == 1 and args.ba_windows > 0:
-            out["local_ba"] = ba_throughput(local_rank, args.ba_windows)
+        if local_ba is not None:
+            out["local_ba"] = local_ba
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

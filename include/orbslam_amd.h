@@ -29,7 +29,7 @@ enum {
     ORB_E_ASPECT = -5,    /* image so tall that the reference's quadtree root count rounds to 0 (the
                              reference divides by zero there, src/ORBextractor.cpp:493-495)           */
     ORB_E_STOPPED = -6,   /* ba_solve: *stop became true before the first iteration                    */
-    ORB_E_SINGULAR = -7   /* ba_solve: linear system could not be solved at any damping               */
+    ORB_E_BUSY = -7       /* ba_submit_batch: two batches already in flight (call ba_wait first)       */
 };
 
 const char *orb_last_error(void);
@@ -206,12 +206,28 @@ typedef struct BAResult {
 } BAResult;
 
 typedef struct BASolver BASolver; /* opaque */
+/* max_batch is enforced (ORB_E_CAPACITY beyond it); max_cams / max_points / max_obs are sizing hints only -- every
+ * buffer grows on demand and there is no limit on the number of cameras (g2o has none either): a reduced system
+ * whose Cholesky panel does not fit the LDS is solved by the in-kernel PCG, with its vectors in HBM if need be. */
 int ba_create(int max_cams, int max_points, int max_obs, int max_batch, int device_id, BASolver **out);
 void ba_destroy(BASolver *s);
-/* Optimizer::BundleAdjustment / LocalBundleAdjustment numerical core */
+/* Optimizer::BundleAdjustment / LocalBundleAdjustment numerical core.  ONE window (the LocalMapping call pattern)
+ * is spread over a team of up to 64 workgroups with device-side barriers between the phases of an iteration. */
 int ba_solve(BASolver *s, const BAProblem *p, BAResult *r);
 /* n independent windows (BASELINE config 3 / target), solved concurrently on the device */
 int ba_solve_batch(BASolver *s, const BAProblem *p, BAResult *r, int n);
+/* The same in two halves, for a steady stream of batches: ba_submit_batch stages the batch on the host and enqueues
+ * its uploads, kernels and download; ba_wait blocks until the OLDEST submitted batch has finished and fills its
+ * BAResult array.  Up to two batches may be in flight, so the host side of batch k+1 and the download of batch k-1
+ * overlap the kernels of batch k.  p / r and everything they point to must stay valid until the matching ba_wait.
+ * A batch that carries a stop flag has to be polled between iterations and runs to completion inside submit. */
+int ba_submit_batch(BASolver *s, const BAProblem *p, BAResult *r, int n);
+int ba_wait(BASolver *s);
+/* measurement hooks: with profiling enabled every LM-iteration launch is bracketed by HIP events on the solver's
+ * stream; after a batch has finished, ba_get_iteration_ms returns the average duration of its k_ba_iteration
+ * launches, their number, and the workgroups per window (team size) they ran with. */
+int ba_set_profiling(BASolver *s, int enable);
+int ba_get_iteration_ms(BASolver *s, float *avg_ms, int32_t *n_launches, int32_t *team);
 
 /* Optimizer::PoseOptimization numerical core (src/Optimizer.cpp:131-261): one free pose, n unary
  * edges with fixed Xw; 4 rounds x 10 iterations with chi2 relabelling; robust kernel dropped after

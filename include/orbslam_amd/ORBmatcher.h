@@ -1,27 +1,54 @@
 /*
  * ORBmatcher.h -- drop-in replacement of the reference's include/ORBmatcher.h:8-32 on top of the MI355X
- * C-ABI.  Same member functions; the class is a template over the Frame type so that it compiles both
- * inside the reference tree (where `Frame` is the reference's class) and in this repo's tests.
+ * C-ABI.  Like the reference header (include/ORBmatcher.h:4) it includes "Frame.h" and then defines
+ * `class ORBSlam::ORBmatcher` with the reference's member functions, so src/Tracking.cpp:181-189
+ *     ORBmatcher matcher(0.9, true);
+ *     matcher.SearchForInitialization(minitialRefFrame, mCurframe, vbPrevMatched, mvIniMatches, 100);
+ * compiles unchanged.  The implementation is the class template ORBmatcherT<FrameT> (usable on its own
+ * where no "Frame.h" is on the include path: define ORBSLAM_AMD_NO_FRAME_INCLUDE or simply do not have one).
  *
- * The reference's Frame keeps its image bounds in PRIVATE statics (include/Frame.h:75) and exposes no
- * getter; the matcher needs them to reproduce GetFeaturesInArea's grid.  INTEGRATION.md shows the
- * one-line accessor to add; until then the bounds default to (0, cols, 0, rows) through
- * ORBmatcher::SetImageBounds (what Frame::FindimageBound computes for an undistorted camera,
- * src/Frame.cpp:113-119).
+ * Image bounds of Frame::GetFeaturesInArea's grid: the reference keeps them in PRIVATE statics
+ * (include/Frame.h:75) with no getter.  Resolution order: (1) ORBmatcher::SetImageBounds, if called;
+ * (2) `static void FrameT::GetImageBounds(float&, float&, float&, float&)` if the Frame type has it (the one-line
+ * accessor INTEGRATION.md shows, needed for DISTORTED cameras only); (3) (0, cols, 0, rows) of the image most
+ * recently given to an ORBextractor -- what Frame::FindimageBound computes for an undistorted camera
+ * (src/Frame.cpp:113-119).  So with the reference as it is, nothing has to be called by hand.
  */
 #ifndef ORBSLAM_AMD_ORBMATCHER_H
 #define ORBSLAM_AMD_ORBMATCHER_H
 
-#include <stdexcept>
+#include <algorithm>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../orbslam_amd.h"
+#include "ORBextractor.h"
 #include "cv_shim.h"
+
+#if !defined(ORBSLAM_AMD_NO_FRAME_INCLUDE) && defined(__has_include)
+#if __has_include("Frame.h")
+#include "Frame.h" /* reference include/ORBmatcher.h:4 */
+#define ORBSLAM_AMD_HAVE_FRAME_H 1
+#endif
+#endif
 
 namespace ORBSlam {
 
-template <class FrameT, class KeyFrameT = void, class MapPointT = void> class ORBmatcherT {
+namespace detail {
+template <class F, class = void> struct has_image_bounds : std::false_type {};
+template <class F>
+struct has_image_bounds<F, decltype(F::GetImageBounds(std::declval<float &>(), std::declval<float &>(), std::declval<float &>(),
+                                                      std::declval<float &>()))> : std::true_type {};
+template <class F> typename std::enable_if<has_image_bounds<F>::value, bool>::type frame_bounds(float *b) {
+    F::GetImageBounds(b[0], b[1], b[2], b[3]);
+    return b[1] > b[0] && b[3] > b[2];
+}
+template <class F> typename std::enable_if<!has_image_bounds<F>::value, bool>::type frame_bounds(float *) { return false; }
+} // namespace detail
+
+template <class FrameT> class ORBmatcherT {
   public:
     ORBmatcherT(float nnratio = 0.6, bool checkOri = true)
         : mfNNratio(nnratio), mbCheckOrientation(checkOri), m_(nullptr), cap_(0) {}
@@ -29,11 +56,14 @@ template <class FrameT, class KeyFrameT = void, class MapPointT = void> class OR
     ORBmatcherT(const ORBmatcherT &) = delete;
     ORBmatcherT &operator=(const ORBmatcherT &) = delete;
 
+    /* optional override of the image bounds (see the header comment) */
     static void SetImageBounds(float minX, float maxX, float minY, float maxY) {
-        bounds()[0] = minX;
-        bounds()[1] = maxX;
-        bounds()[2] = minY;
-        bounds()[3] = maxY;
+        float *b = explicit_bounds();
+        b[0] = minX;
+        b[1] = maxX;
+        b[2] = minY;
+        b[3] = maxY;
+        b[4] = 1.f;
     }
 
     /* reference src/ORBmatcher.cpp:9-126 */
@@ -42,21 +72,21 @@ template <class FrameT, class KeyFrameT = void, class MapPointT = void> class OR
         const std::vector<cv::KeyPoint> &k1 = F1.GetUnKeyPts();
         const std::vector<cv::KeyPoint> &k2 = F2.GetUnKeyPts();
         const cv::Mat d1 = F1.GetDescriptors(), d2 = F2.GetDescriptors(); /* ONE clone each, not one per use */
-        vnMatches12.assign(k1.size(), -1);
+        vnMatches12.assign(k1.size(), -1);                                  /* :13 */
         if (k1.empty()) return 0;
         ensure((int)std::max(k1.size(), k2.size()));
         std::vector<unsigned char> b1(k1.size() * 32), b2(k2.size() * 32);
         for (size_t i = 0; i < k1.size(); i++) memcpy(&b1[i * 32], d1.ptr((int)i), 32);
         for (size_t i = 0; i < k2.size(); i++) memcpy(&b2[i * 32], d2.ptr((int)i), 32);
-        OrbFrameView v1 = {(const OrbKeyPoint *)k1.data(), b1.data(), (int32_t)k1.size(), bounds()[0], bounds()[1],
-                           bounds()[2], bounds()[3]};
-        OrbFrameView v2 = {(const OrbKeyPoint *)k2.data(), b2.data(), (int32_t)k2.size(), bounds()[0], bounds()[1],
-                           bounds()[2], bounds()[3]};
+        float b[4];
+        bounds(b);
+        OrbFrameView v1 = {(const OrbKeyPoint *)k1.data(), b1.data(), (int32_t)k1.size(), b[0], b[1], b[2], b[3]};
+        OrbFrameView v2 = {(const OrbKeyPoint *)k2.data(), b2.data(), (int32_t)k2.size(), b[0], b[1], b[2], b[3]};
         static_assert(sizeof(cv::Point2f) == 8, "cv::Point2f must be two floats");
         int32_t n = 0;
-        int rc = orb_match_init(m_, &v1, &v2, (float *)vbPrevMatched.data(), vnMatches12.data(), windowSize, mfNNratio,
-                                mbCheckOrientation ? 1 : 0, &n);
-        if (rc != ORB_OK) throw std::runtime_error("ORBmatcher::SearchForInitialization failed");
+        if (orb_match_init(m_, &v1, &v2, (float *)vbPrevMatched.data(), vnMatches12.data(), windowSize, mfNNratio,
+                           mbCheckOrientation ? 1 : 0, &n) != ORB_OK)
+            orbslam_amd_fatal("ORBmatcher::SearchForInitialization");
         return n;
     }
 
@@ -74,21 +104,38 @@ template <class FrameT, class KeyFrameT = void, class MapPointT = void> class OR
         ind3 = c;
     }
 
-    /* empty-bodied stubs in the reference (include/ORBmatcher.h:22,24): kept as explicit "no matches" */
-    template <class KF, class MP> int SearchByBoW(KF *, FrameT, std::vector<MP *> &) { return 0; }
+    /* empty-bodied in the reference (include/ORBmatcher.h:22,24 -- `{}` with an int return type, i.e. no defined
+     * result): kept as explicit "no matches".  SURVEY N4: nothing in the reference to be identical to. */
+    template <class KF, class MP> int SearchByBoW(KF *, const FrameT &, std::vector<MP *> &) { return 0; }
     int SearchByProjection(FrameT &, const FrameT &, const float, const bool) { return 0; }
 
-  private:
-    static float *bounds() {
-        static float b[4] = {0.f, 640.f, 0.f, 480.f};
+  protected:
+    static float *explicit_bounds() {
+        static float b[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
         return b;
+    }
+    static void bounds(float *b) {
+        const float *e = explicit_bounds();
+        if (e[4] != 0.f) {
+            for (int i = 0; i < 4; i++) b[i] = e[i];
+            return;
+        }
+        if (detail::frame_bounds<FrameT>(b)) return;
+        b[0] = 0.f;
+        b[1] = (float)LastExtractedImageSize()[0];
+        b[2] = 0.f;
+        b[3] = (float)LastExtractedImageSize()[1];
+        if (!(b[1] > 0.f && b[3] > 0.f)) { /* no extractor ran in this process: VGA, the reference's test camera */
+            b[1] = 640.f;
+            b[3] = 480.f;
+        }
     }
     void ensure(int n) {
         if (m_ && n <= cap_) return;
         orb_matcher_destroy(m_);
         m_ = nullptr;
         cap_ = n < 4096 ? 4096 : n;
-        if (orb_matcher_create(cap_, 1, 0, &m_) != ORB_OK) throw std::runtime_error("ORBmatcher: no HIP device");
+        if (orb_matcher_create(cap_, 1, 0, &m_) != ORB_OK) orbslam_amd_fatal("ORBmatcher");
     }
     static const int HISTO_LENGTH = 30;
     static const int TH_LOW = 50;
@@ -97,6 +144,14 @@ template <class FrameT, class KeyFrameT = void, class MapPointT = void> class OR
     OrbMatcher *m_;
     int cap_;
 };
+
+#ifdef ORBSLAM_AMD_HAVE_FRAME_H
+/* the reference's class, by its own name (include/ORBmatcher.h:8) */
+class ORBmatcher : public ORBmatcherT<Frame> {
+  public:
+    ORBmatcher(float nnratio = 0.6, bool checkOri = true) : ORBmatcherT<Frame>(nnratio, checkOri) {}
+};
+#endif
 
 } // namespace ORBSlam
 #endif

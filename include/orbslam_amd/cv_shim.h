@@ -1,7 +1,7 @@
 /*
  * cv_shim.h -- the small subset of OpenCV types that the reference's hot-path signatures mention
- * (cv::Mat, cv::KeyPoint, cv::Point2f, cv::InputArray / cv::OutputArray, CV_8UC1), for builds where
- * OpenCV is not installed (this image has none).  With real OpenCV available define
+ * (cv::Mat, cv::KeyPoint, cv::Point2f, cv::Rect, cv::InputArray / cv::OutputArray, CV_8UC1, CV_32F), for builds
+ * where OpenCV is not installed (this image has none).  With real OpenCV available define
  * ORBSLAM_AMD_USE_OPENCV before including the drop-in headers and this file forwards to it instead.
  */
 #ifndef ORBSLAM_AMD_CV_SHIM_H
@@ -21,6 +21,9 @@
 #define CV_8U 0
 #define CV_8UC1 0
 #define CV_32F 5
+#define CV_32FC1 5
+#define CV_64F 6
+#define CV_64FC1 6
 
 namespace cv {
 
@@ -44,6 +47,12 @@ struct Size {
     Size(int w, int h) : width(w), height(h) {}
 };
 
+struct Rect {
+    int x, y, width, height;
+    Rect() : x(0), y(0), width(0), height(0) {}
+    Rect(int x_, int y_, int w, int h) : x(x_), y(y_), width(w), height(h) {}
+};
+
 /* 28-byte POD, layout-compatible with OrbKeyPoint of the C-ABI */
 struct KeyPoint {
     Point2f pt;
@@ -54,23 +63,29 @@ struct KeyPoint {
         : pt(x, y), size(s), angle(a), response(r), octave(o), class_id(c) {}
 };
 
-/* reference-counted 2-D 8-bit matrix (single channel), enough for images and N x 32 descriptors */
+/* reference-counted 2-D single-channel matrix (8U / 32F / 64F), enough for images, N x 32 descriptors and the
+ * 3 x 3 camera matrix of Frame::GetCameraPara; an ROI shares its parent's buffer like cv::Mat(m, rect) */
 class Mat {
   public:
     int rows, cols;
     size_t step;
     unsigned char *data;
-    Mat() : rows(0), cols(0), step(0), data(nullptr) {}
-    Mat(int r, int c, int type) : rows(0), cols(0), step(0), data(nullptr) { create(r, c, type); }
-    Mat(int r, int c, int /*type*/, void *ext, size_t stp = 0)
-        : rows(r), cols(c), step(stp ? stp : (size_t)c), data((unsigned char *)ext) {}
-    void create(int r, int c, int /*type*/) {
-        if (r == rows && c == cols && buf_) return;
+    Mat() : rows(0), cols(0), step(0), data(nullptr), type_(CV_8UC1) {}
+    Mat(int r, int c, int type) : rows(0), cols(0), step(0), data(nullptr), type_(CV_8UC1) { create(r, c, type); }
+    Mat(int r, int c, int type, void *ext, size_t stp = 0)
+        : rows(r), cols(c), step(stp ? stp : (size_t)c * esz(type)), data((unsigned char *)ext), type_(type) {}
+    Mat(const Mat &m, const Rect &roi)
+        : rows(roi.height), cols(roi.width), step(m.step), data(m.data + (size_t)roi.y * m.step + (size_t)roi.x * esz(m.type_)),
+          type_(m.type_), buf_(m.buf_) {}
+    Mat operator()(const Rect &roi) const { return Mat(*this, roi); }
+    void create(int r, int c, int type) {
+        if (r == rows && c == cols && type == type_ && buf_ && step == (size_t)c * esz(type)) return;
         rows = r;
         cols = c;
-        step = (size_t)c;
-        buf_ = std::shared_ptr<unsigned char>(new unsigned char[(size_t)r * c > 0 ? (size_t)r * c : 1],
-                                              std::default_delete<unsigned char[]>());
+        type_ = type;
+        step = (size_t)c * esz(type);
+        const size_t n = (size_t)r * step;
+        buf_ = std::shared_ptr<unsigned char>(new unsigned char[n > 0 ? n : 1], std::default_delete<unsigned char[]>());
         data = buf_.get();
     }
     void release() {
@@ -80,12 +95,13 @@ class Mat {
         step = 0;
     }
     bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
-    int type() const { return CV_8UC1; }
+    int type() const { return type_; }
+    size_t elemSize() const { return esz(type_); }
     Mat clone() const {
         Mat m;
         if (!empty()) {
-            m.create(rows, cols, CV_8UC1);
-            for (int y = 0; y < rows; y++) memcpy(m.data + (size_t)y * m.step, data + (size_t)y * step, cols);
+            m.create(rows, cols, type_);
+            for (int y = 0; y < rows; y++) memcpy(m.data + (size_t)y * m.step, data + (size_t)y * step, (size_t)cols * esz(type_));
         }
         return m;
     }
@@ -104,6 +120,8 @@ class Mat {
     Mat getMat() const { return *this; }
 
   private:
+    static size_t esz(int type) { return type == CV_32F ? 4 : (type == CV_64F ? 8 : 1); }
+    int type_;
     std::shared_ptr<unsigned char> buf_;
 };
 

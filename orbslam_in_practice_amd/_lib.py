@@ -16,10 +16,10 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4
                      ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
 assert KP_DTYPE.itemsize == 28
 
-ORB_OK, ORB_E_INVALID, ORB_E_CAPACITY, ORB_E_NO_DEVICE, ORB_E_HIP, ORB_E_ASPECT, ORB_E_STOPPED, ORB_E_SINGULAR = \
+ORB_OK, ORB_E_INVALID, ORB_E_CAPACITY, ORB_E_NO_DEVICE, ORB_E_HIP, ORB_E_ASPECT, ORB_E_STOPPED, ORB_E_BUSY = \
     0, -1, -2, -3, -4, -5, -6, -7
 _ERR_NAMES = {-1: "ORB_E_INVALID", -2: "ORB_E_CAPACITY", -3: "ORB_E_NO_DEVICE", -4: "ORB_E_HIP",
-              -5: "ORB_E_ASPECT", -6: "ORB_E_STOPPED", -7: "ORB_E_SINGULAR"}
+              -5: "ORB_E_ASPECT", -6: "ORB_E_STOPPED", -7: "ORB_E_BUSY"}
 
 
 class OrbError(RuntimeError):
@@ -61,7 +61,8 @@ EXPORTS = [
     "orb_set_profiling", "orb_get_stage_ms", "orb_matcher_set_profiling", "orb_matcher_get_ms", "orb_matcher_get_stage_ms", "orb_features_in_area",
     "orb_descriptor_distance", "orb_compute_three_maxima", "orb_matcher_create", "orb_matcher_destroy",
     "orb_matcher_stream", "orb_matcher_synchronize", "orb_hamming_knn2", "orb_match_init",
-    "orb_match_batch_device", "ba_create", "ba_destroy", "ba_solve", "ba_solve_batch", "ba_pose_optimization", "ba_pose_optimization_batch",
+    "orb_match_batch_device", "ba_create", "ba_destroy", "ba_solve", "ba_solve_batch", "ba_submit_batch", "ba_wait", "ba_set_profiling", "ba_get_iteration_ms",
+    "ba_pose_optimization", "ba_pose_optimization_batch",
 ]
 
 _lib = None
@@ -126,6 +127,10 @@ def lib():
     L.ba_destroy.restype = None
     L.ba_solve.argtypes = [vp, C.POINTER(BAProblem), C.POINTER(BAResult)]
     L.ba_solve_batch.argtypes = [vp, C.POINTER(BAProblem), C.POINTER(BAResult), i32]
+    L.ba_submit_batch.argtypes = [vp, C.POINTER(BAProblem), C.POINTER(BAResult), i32]
+    L.ba_wait.argtypes = [vp]
+    L.ba_set_profiling.argtypes = [vp, i32]
+    L.ba_get_iteration_ms.argtypes = [vp, vp, vp, vp]
     L.ba_pose_optimization.argtypes = [vp, vp, vp, vp, vp, i32, C.c_double, C.c_double, C.c_double, C.c_double,
                                        vp, vp]
     L.ba_pose_optimization_batch.argtypes = [vp, vp, vp, vp, vp, vp, i32, C.c_double, C.c_double, C.c_double,

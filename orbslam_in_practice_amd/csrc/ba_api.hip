@@ -42,7 +42,8 @@
 
 #define BA_T 512
 #define BA_W (BA_T / 64)
-#define BA_MAX_N 1536 /* reduced system size (6 * free cameras) that fits the LDS vectors */
+#define BA_MAX_N 1536 /* reduced system size (6 * free cameras) whose PCG vectors fit the static LDS arrays */
+#define BA_GMAX 64    /* most workgroups that may team up on one window */
 
 static OrbErrSlot b_err; /* forwards to orb_last_error() */
 #define BCHK(expr)                                                          \
@@ -65,6 +66,9 @@ struct BAWin {
     /* ints */
     int64_t cam, pt, pt_start, cam_start, cam_edges, slot, blk_row, blk_col, blk_diag, blk_mirror, blk_upper, blk_rowid, con_start, con_e1, con_e2;
     int64_t ch_first, ch_last; /* Cholesky envelope per 16-row tile: first tile column of tile row i (non-decreasing), last tile row that reaches tile column k */
+    int64_t gbar;              /* ints: two arrival counters of the window's workgroup team (alternating per launch) */
+    int64_t gred;              /* doubles (scratch): 2 slots x 2 values x BA_GMAX partial sums of the team */
+    int64_t pcgv;              /* doubles (scratch): x, r, z, p, Ap of a PCG whose vectors exceed the LDS arrays (n > BA_MAX_N) */
     /* bytes */
     int64_t flags; /* per edge: bit0 active, bit1 robust */
 };
@@ -250,16 +254,92 @@ __device__ __forceinline__ double block_max(double v, BAShared &s) {
     return t;
 }
 
+/* ------------------------------------------------------------------------------------------------------------
+ * A TEAM of G workgroups per window (G == 1: the batch path, one workgroup per window, nothing below costs
+ * anything).  LocalMapping hands over ONE window per keyframe; with one workgroup that window runs on one of 256
+ * CUs.  With a team, every streaming phase (chi2, Hll/W, Hpp, Dinv/Y, Schur blocks, g, back-substitution) is strided
+ * over G x 512 threads and the phases are separated by a team barrier: an arrival counter in global memory
+ * (agent-scope atomics; release/acquire fences write back / invalidate the XCD-private L2 so that the parts, which
+ * land on different XCDs, see each other's data).  The team is launched cooperatively (all G x windows workgroups
+ * co-resident), so the barrier cannot deadlock.  Sums over the team are partial sums per workgroup combined in part
+ * order: deterministic, and for G == 1 bit-identical to the single-workgroup code. */
+struct BATeam {
+    int G, part;
+    unsigned *bar;  /* this launch's arrival counter */
+    unsigned epoch; /* barriers passed so far in this launch (uniform) */
+    double *red;    /* [2 slots][2 values][BA_GMAX] */
+    int slot;
+};
+__device__ __forceinline__ void team_sync(BATeam &t) {
+    if (t.G == 1) {
+        __syncthreads();
+        return;
+    }
+    __threadfence(); /* release: this thread's stores reach device scope */
+    __syncthreads();
+    t.epoch++;
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(t.bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = t.epoch * (unsigned)t.G;
+        while (__hip_atomic_load(t.bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();
+    __threadfence(); /* acquire: later loads of every wave see the other parts' stores */
+}
+/* sums of a and b over all threads of the team (b may be unused) */
+__device__ __forceinline__ void team_sum2(double &a, double &b, BAShared &s, BATeam &t) {
+    a = block_sum(a, s);
+    b = block_sum(b, s);
+    if (t.G == 1) return;
+    double *r = t.red + t.slot * 2 * BA_GMAX;
+    t.slot ^= 1;
+    if (threadIdx.x == 0) {
+        r[t.part] = a;
+        r[BA_GMAX + t.part] = b;
+    }
+    team_sync(t);
+    double ta = 0, tb = 0;
+    for (int g = 0; g < t.G; g++) {
+        ta += __hip_atomic_load(r + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tb += __hip_atomic_load(r + BA_GMAX + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    a = ta;
+    b = tb;
+}
+__device__ __forceinline__ double team_sum(double v, BAShared &s, BATeam &t) {
+    if (t.G == 1) return block_sum(v, s);
+    double z = 0;
+    v = block_sum(v, s);
+    double *r = t.red + t.slot * 2 * BA_GMAX;
+    t.slot ^= 1;
+    if (threadIdx.x == 0) r[t.part] = v;
+    team_sync(t);
+    for (int g = 0; g < t.G; g++) z += __hip_atomic_load(r + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return z;
+}
+__device__ __forceinline__ double team_max(double v, BAShared &s, BATeam &t) {
+    v = block_max(v, s);
+    if (t.G == 1) return v;
+    double *r = t.red + t.slot * 2 * BA_GMAX;
+    t.slot ^= 1;
+    if (threadIdx.x == 0) r[t.part] = v;
+    team_sync(t);
+    double z = __hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int g = 1; g < t.G; g++) z = fmax(z, __hip_atomic_load(r + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return z;
+}
+
 /* errors of all active edges at (poses, pts) -> err ; returns robust chi2 (activeRobustChi2) */
-__device__ double eval_chi2(const BAWin &w, double *D, const int32_t *I, const uint8_t *B, int64_t poses, int64_t pts,
-                            int64_t err, BAShared &s) {
+__device__ double eval_chi2_partial(const BAWin &w, double *D, const int32_t *I, const uint8_t *B, int64_t poses, int64_t pts,
+                                    int64_t err, const BATeam &t) {
     /* two edges per step, every index / flag / observation load issued before the first dependent gather and none of
        them behind the "inactive edge" branch (inactive edges are computed and discarded): a quarter of the dependent
        memory round trips of the plain loop.  Same per-thread summation order (e, e + T, e + 2T, ...). */
     double acc = 0;
-    for (int e0 = threadIdx.x; e0 < w.E; e0 += 2 * BA_T) {
-        const int eA = e0, eB = (e0 + BA_T < w.E) ? e0 + BA_T : e0;
-        const bool vB = e0 + BA_T < w.E;
+    const int TT = t.G * BA_T; /* threads of the team */
+    for (int e0 = t.part * BA_T + threadIdx.x; e0 < w.E; e0 += 2 * TT) {
+        const int eA = e0, eB = (e0 + TT < w.E) ? e0 + TT : e0;
+        const bool vB = e0 + TT < w.E;
         const uint8_t fA = B[w.flags + eA], fB = B[w.flags + eB];
         const int cA = I[w.cam + eA], cB = I[w.cam + eB], pA = I[w.pt + eA], pB = I[w.pt + eB];
         const double iA = D[w.info + eA], iB = D[w.info + eB];
@@ -283,7 +363,7 @@ __device__ double eval_chi2(const BAWin &w, double *D, const int32_t *I, const u
             acc += c;
         }
     }
-    return block_sum(acc, s);
+    return acc;
 }
 
 
@@ -489,25 +569,114 @@ __device__ __noinline__ bool ba_chol_solve(const BAWin &w, double *D, const int3
     return ok;
 }
 
+/* PCG on S x = g for a reduced system whose vectors do not fit the LDS arrays (more than 256 free cameras AND an
+ * envelope too wide for the Cholesky panel: a large, nearly dense global BA).  Same algorithm, preconditioner,
+ * tolerance and iteration cap as the LDS version below; x, r, z, p, Ap live in global scratch.  One workgroup. */
+__device__ __noinline__ bool ba_pcg_global(const BAWin &w, double *D, const int32_t *I, int n, double pcg_tol2, int pcg_maxit,
+                                           bool minv_ok, int *iters, BAShared &s) {
+    const int tid = threadIdx.x;
+    double *x = D + w.pcgv, *r = x + n, *z = r + n, *pv = z + n, *Ap = pv + n;
+    auto precond = [&](double &rz_out) { /* z = M^-1 r, returns r.z */
+        double loc = 0;
+        for (int i = tid; i < n; i += BA_T) {
+            const int sl = i / 6, a = i % 6;
+            const double *Mi = D + w.Minv + (int64_t)sl * 36 + a * 6;
+            double v = 0;
+            for (int c = 0; c < 6; c++) v += Mi[c] * r[sl * 6 + c];
+            z[i] = v;
+            loc += r[i] * v;
+        }
+        rz_out = block_sum(loc, s);
+    };
+    for (int i = tid; i < n; i += BA_T) {
+        x[i] = 0.0;
+        r[i] = D[w.g + i];
+    }
+    __syncthreads();
+    double rz;
+    precond(rz);
+    for (int i = tid; i < n; i += BA_T) pv[i] = z[i];
+    __syncthreads();
+    const double rz0 = rz;
+    bool ok = block_sum(minv_ok ? 0.0 : 1.0, s) == 0.0;
+    int it = 0;
+    if (ok && rz0 > 0) {
+        for (it = 0; it < pcg_maxit; it++) {
+            double loc = 0;
+            for (int i = tid; i < n; i += BA_T) {
+                const int sl = i / 6, a = i % 6;
+                double v = 0;
+                for (int bk = I[w.blk_row + sl]; bk < I[w.blk_row + sl + 1]; bk++) {
+                    const double *Sr = D + w.S + (int64_t)bk * 36 + a * 6;
+                    const double *pc = pv + I[w.blk_col + bk] * 6;
+                    v += Sr[0] * pc[0] + Sr[1] * pc[1] + Sr[2] * pc[2] + Sr[3] * pc[3] + Sr[4] * pc[4] + Sr[5] * pc[5];
+                }
+                Ap[i] = v;
+                loc += pv[i] * v;
+            }
+            const double pAp = block_sum(loc, s);
+            if (!(pAp > 0)) {
+                ok = false;
+                break;
+            }
+            const double alpha = rz / pAp;
+            for (int i = tid; i < n; i += BA_T) {
+                x[i] += alpha * pv[i];
+                r[i] -= alpha * Ap[i];
+            }
+            __syncthreads();
+            double rz_new;
+            precond(rz_new);
+            if (rz_new <= pcg_tol2 * rz0) {
+                it++;
+                break;
+            }
+            const double beta = rz_new / rz;
+            rz = rz_new;
+            for (int i = tid; i < n; i += BA_T) pv[i] = z[i] + beta * pv[i];
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < n; i += BA_T) D[w.x + i] = ok ? x[i] : 0.0;
+    *iters = it;
+    return ok;
+}
+
 /* one LM iteration (OptimizationAlgorithmLevenberg::solve) for every window of the batch */
 __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of_round, double pcg_tol2, int pcg_maxit,
-                                                       int debug, int solver, int dyn_doubles) {
+                                                       int debug, int solver, int dyn_doubles, int G, int launch_seq) {
     __shared__ BAShared s;
     extern __shared__ __attribute__((aligned(16))) double ba_dyn[];
-    const BAWin &w = bufs.wins[blockIdx.x]; /* by reference: the ~110-dword descriptor stays in memory (scalar cache), not in registers */
+    /* workgroups [win * G, win * G + G) are the team of window `win` */
+    const int win = __builtin_amdgcn_readfirstlane((int)blockIdx.x / G);
+    const BAWin &w = bufs.wins[win]; /* by reference: the ~110-dword descriptor stays in memory (scalar cache), not in registers */
     double *D = bufs.D;
     const int32_t *I = bufs.I;
     const uint8_t *B = bufs.B;
     double *st = D + w.st;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); /* uniform: scalar unit */
-    if (st[ST_TERM] != 0.0) return; /* uniform: this window's round already terminated */
+    BATeam team;
+    team.G = G;
+    team.part = __builtin_amdgcn_readfirstlane((int)blockIdx.x - win * G);
+    team.bar = (unsigned *)(bufs.I + w.gbar) + (launch_seq & 1);
+    team.epoch = 0;
+    team.red = D + w.gred;
+    team.slot = 0;
+    /* the OTHER arrival counter serves the next launch and nobody is using it now; every launch clears it, also one
+       that returns on the next line, so that a launch always finds its own counter at zero */
+    if (G > 1 && team.part == 0 && tid == 0)
+        __hip_atomic_store((unsigned *)(bufs.I + w.gbar) + ((launch_seq + 1) & 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (st[ST_TERM] != 0.0) return; /* uniform over the team: this window's round already terminated */
+    const int gtid = team.part * BA_T + tid, gthreads = G * BA_T; /* thread / wavefront index within the team */
+    const int gwave = team.part * BA_W + wave, gwaves = G * BA_W;
+    const bool lead = team.part == 0;
     const int n = w.Ncf * 6;
     /* profile mode: thread 0 accumulates wall time per phase (diagnostic build path only, never in timed runs) */
     unsigned long long t_prev = debug ? __builtin_amdgcn_s_memrealtime() : 0ull;
 #define BA_STAMP(slot)                                                        \
     if (debug) {                                                              \
         __syncthreads();                                                      \
-        if (tid == 0) {                                                       \
+        if (tid == 0 && blockIdx.x % G == 0) {                                \
             const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); \
             st[ST_T0 + (slot)] += (double)(t_now - t_prev);                   \
             t_prev = t_now;                                                   \
@@ -515,16 +684,16 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
     }
 
     /* ---- computeActiveErrors + activeRobustChi2 ---- */
-    double currentChi = eval_chi2(w, D, I, B, w.poses, w.pts, w.err, s);
-    if (tid == 0 && st[ST_HAVE_CHI0] == 0.0) {
+    double currentChi = team_sum(eval_chi2_partial(w, D, I, B, w.poses, w.pts, w.err, team), s, team);
+    if (lead && tid == 0 && st[ST_HAVE_CHI0] == 0.0) {
         st[ST_CHI0] = currentChi;
         st[ST_HAVE_CHI0] = 1.0;
     }
-    __syncthreads();
+    if (G == 1) __syncthreads(); /* (the team's sum already ended in a barrier) */
 
     BA_STAMP(0)
     /* ---- buildSystem: Hll, bl, W (thread per point) ---- */
-    for (int p = tid; p < w.Np; p += BA_T) {
+    for (int p = gtid; p < w.Np; p += gthreads) {
         double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
         const int e0 = I[w.pt_start + p], e1 = I[w.pt_start + p + 1];
         /* software pipeline over the point's edges: flag, camera id, residual and information of the NEXT edge are
@@ -585,7 +754,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
     }
     BA_STAMP(1)
     /* ---- Hpp, bp: one wavefront per free camera, lanes over its edges, shuffle reduction ---- */
-    for (int c = wave; c < w.Nc; c += BA_W) {
+    for (int c = gwave; c < w.Nc; c += gwaves) {
         const int sl = I[w.slot + c];
         if (sl < 0) continue;
         double acc[27];
@@ -635,16 +804,16 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
             for (int a = 0; a < 6; a++) D[w.bp + (int64_t)sl * 6 + a] = acc[21 + a];
         }
     }
-    __syncthreads();
+    team_sync(team);
 
     BA_STAMP(2)
     /* ---- computeLambdaInit on the first iteration of an optimize() call ---- */
     double lambda = st[ST_LAMBDA], ni = st[ST_NI];
     if (first_of_round) {
         double m = 0;
-        for (int i = tid; i < w.Ncf * 6; i += BA_T) m = fmax(m, fabs(D[w.Hpp + (int64_t)(i / 6) * 36 + (i % 6) * 7]));
-        for (int i = tid; i < w.Np * 3; i += BA_T) m = fmax(m, fabs(D[w.Hll + (int64_t)(i / 3) * 9 + (i % 3) * 4]));
-        m = block_max(m, s);
+        for (int i = gtid; i < w.Ncf * 6; i += gthreads) m = fmax(m, fabs(D[w.Hpp + (int64_t)(i / 6) * 36 + (i % 6) * 7]));
+        for (int i = gtid; i < w.Np * 3; i += gthreads) m = fmax(m, fabs(D[w.Hll + (int64_t)(i / 3) * 9 + (i % 3) * 4]));
+        m = team_max(m, s, team);
         lambda = 1e-5 * m;
         ni = 2;
     }
@@ -654,7 +823,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
     int solves = 0, pcg_total = 0;
     do {
         /* ---- Dinv = (Hll + lambda I)^-1, Y = W Dinv (thread per point) ---- */
-        for (int p = tid; p < w.Np; p += BA_T) {
+        for (int p = gtid; p < w.Np; p += gthreads) {
             double Dm[9];
             for (int i = 0; i < 9; i++) Dm[i] = D[w.Hll + (int64_t)p * 9 + i];
             Dm[0] += lambda;
@@ -675,9 +844,9 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
             Iv[8] = (Dm[0] * Dm[4] - Dm[1] * Dm[3]) * id;
             for (int i = 0; i < 9; i++) D[w.Dinv + (int64_t)p * 9 + i] = Iv[i];
         }
-        __syncthreads();
+        team_sync(team);
         /* Y = W Dinv, one thread per (edge, row of W): neighbouring threads touch neighbouring 24-B rows */
-        for (int t = tid; t < w.E * 6; t += BA_T) {
+        for (int t = gtid; t < w.E * 6; t += gthreads) {
             const int e = t / 6, a = t - e * 6;
             const double *Wr = D + w.W + (int64_t)e * 18 + a * 3;
             const double *Iv = D + w.Dinv + (int64_t)I[w.pt + e] * 9;
@@ -687,7 +856,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
             Yr[1] = w0 * Iv[1] + w1 * Iv[4] + w2 * Iv[7];
             Yr[2] = w0 * Iv[2] + w1 * Iv[5] + w2 * Iv[8];
         }
-        __syncthreads();
+        team_sync(team);
         BA_STAMP(3)
         /* ---- S = Hpp + lambda I - sum Y W^T : one wavefront per non-zero 6x6 block.  Each LANE takes whole
            contributions (stride 64: 64 independent Y/W gathers in flight), accumulates its own 6x6 partial in
@@ -696,7 +865,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
         /* four blocks per wavefront: 16 lanes per block (16 independent Y/W gathers in flight per block, 64 per
            wave), so the per-block reduction is a 4-step butterfly inside a 16-lane row instead of 6 steps over
            the whole wave */
-        for (int u0 = wave * 4; u0 < w.nub; u0 += BA_W * 4) {
+        for (int u0 = gwave * 4; u0 < w.nub; u0 += gwaves * 4) {
             const int sub = lane >> 4, l16 = lane & 15;
             const int bk = (u0 + sub < w.nub) ? I[w.blk_upper + u0 + sub] : w.nnzb; /* upper blocks only */
             double acc[36];
@@ -744,18 +913,18 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
                 for (int i = 0; i < 36; i++) D[w.S + (int64_t)bk * 36 + i] = -acc[i];
             }
         }
-        __syncthreads();
+        team_sync(team);
         /* S is symmetric: only blocks on or above the diagonal carry contribution lists; the others are the
            transposes of their mirrors */
-        for (int i = tid; i < w.nnzb * 36; i += BA_T) {
+        for (int i = gtid; i < w.nnzb * 36; i += gthreads) {
             const int bk = i / 36, e = i - bk * 36;
             const int mk = I[w.blk_mirror + bk];
             if (mk < bk) D[w.S + i] = D[w.S + (int64_t)mk * 36 + (e % 6) * 6 + e / 6];
         }
-        __syncthreads();
+        team_sync(team);
         BA_STAMP(4)
         /* diagonal blocks: + Hpp + lambda I (thread per entry) */
-        for (int i = tid; i < w.Ncf * 36; i += BA_T) {
+        for (int i = gtid; i < w.Ncf * 36; i += gthreads) {
             const int sl = i / 36, e = i - sl * 36;
             double v = D[w.Hpp + i];
             if (e % 7 == 0) v += lambda;
@@ -763,7 +932,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
         }
         /* g = bp - sum_e Y_e bl : one wavefront per free camera, lanes over its edges (independent gathers),
            six shuffle reductions */
-        for (int sl = wave; sl < w.Ncf; sl += BA_W) {
+        for (int sl = gwave; sl < w.Ncf; sl += gwaves) {
             const int cam = I[w.blk_row + w.Ncf + 1 + sl]; /* slot -> camera (stored behind the row starts) */
             const int k0 = I[w.cam_start + cam], k1 = I[w.cam_start + cam + 1];
             double acc[6] = {0, 0, 0, 0, 0, 0};
@@ -792,14 +961,15 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
             if (lane == 0)
                 for (int a = 0; a < 6; a++) D[w.g + sl * 6 + a] = D[w.bp + (int64_t)sl * 6 + a] - acc[a];
         }
-        __syncthreads();
+        team_sync(team);
         BA_STAMP(5)
         bool ok2 = true;
         int it = 0;
+        if (lead) { /* the linear solve runs on the team's first workgroup; the others wait at the barrier below */
         /* linear solver of the reduced camera system: dense blocked Cholesky (MFMA f64) when its LDS panel fits,
            PCG otherwise / on request */
         const int np_ = (n + 15) & ~15;
-        const bool use_chol = solver == 1 && n > 0 && (w.ch_pm * CH_LD + 2 * 16 * CH_LD + np_) <= dyn_doubles;
+        const bool use_chol = solver == 1 && n > 0 && w.ch_pm > 0 && (w.ch_pm * CH_LD + 2 * 16 * CH_LD + np_) <= dyn_doubles;
         if (use_chol) {
             BA_STAMP(5)
             ok2 = ba_chol_solve(w, D, I, n, ba_dyn, s);
@@ -862,6 +1032,12 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
                 }
         }
         BA_STAMP(6)
+        if (n > BA_MAX_N) {
+            __syncthreads();
+            ok2 = ba_pcg_global(w, D, I, n, pcg_tol2, pcg_maxit, ok_local, &it, s);
+            pcg_total += it;
+            solves++;
+        } else {
         /* ---- PCG on S x = g ---- */
         double xi[3] = {0, 0, 0}, ri[3], zi[3], pi[3]; /* each thread owns rows tid, tid+BA_T, tid+2*BA_T */
         double rz_loc = 0, gg_loc = 0;
@@ -959,12 +1135,16 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
             const int i = tid + q * BA_T;
             if (i < n) D[w.x + i] = ok2 ? xi[q] : 0.0;
         }
+        } /* LDS-resident PCG */
         }
-        __syncthreads();
+        if (G > 1 && tid == 0) D[w.xl] = ok2 ? 1.0 : 0.0;
+        } /* lead */
+        team_sync(team);
+        if (G > 1) ok2 = __hip_atomic_load(D + w.xl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0;
         BA_STAMP(7)
         /* ---- back-substitution: xl = Dinv (bl - sum_e W_e^T x_c) (thread per point) + trial update ---- */
         double scale_loc = 0;
-        for (int p = tid; p < w.Np; p += BA_T) {
+        for (int p = gtid; p < w.Np; p += gthreads) {
             double cl[3] = {D[w.bl + (int64_t)p * 3], D[w.bl + (int64_t)p * 3 + 1], D[w.bl + (int64_t)p * 3 + 2]};
             const int e0 = I[w.pt_start + p], e1 = I[w.pt_start + p + 1];
             for (int e = e0; e < e1; e++) {
@@ -982,7 +1162,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
                 scale_loc += v * (lambda * v + D[w.bl + (int64_t)p * 3 + a]);
             }
         }
-        for (int c = tid; c < w.Nc; c += BA_T) {
+        for (int c = gtid; c < w.Nc; c += gthreads) {
             const int sl = I[w.slot + c];
             if (sl >= 0 && ok2) {
                 double u[6];
@@ -995,11 +1175,12 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
                 for (int a = 0; a < 7; a++) D[w.poses_t + (int64_t)c * 7 + a] = D[w.poses + (int64_t)c * 7 + a];
             }
         }
-        __syncthreads();
+        team_sync(team);
         BA_STAMP(8)
-        double tempChi = eval_chi2(w, D, I, B, w.poses_t, w.pts_t, w.err_t, s);
+        double tempChi = eval_chi2_partial(w, D, I, B, w.poses_t, w.pts_t, w.err_t, team);
+        double scale = scale_loc;
+        team_sum2(tempChi, scale, s, team);
         if (!ok2) tempChi = 1.7976931348623157e308;
-        double scale = block_sum(scale_loc, s);
         if (!ok2) scale = 0;
         scale += 1e-3;
         rho = (currentChi - tempChi) / scale;
@@ -1009,9 +1190,9 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
             lambda *= fmax(1. / 3., alpha);
             ni = 2;
             currentChi = tempChi;
-            for (int i = tid; i < w.Nc * 7; i += BA_T) D[w.poses + i] = D[w.poses_t + i];
-            for (int i = tid; i < w.Np * 3; i += BA_T) D[w.pts + i] = D[w.pts_t + i];
-            for (int i = tid; i < w.E * 2; i += BA_T) D[w.err + i] = D[w.err_t + i];
+            for (int i = gtid; i < w.Nc * 7; i += gthreads) D[w.poses + i] = D[w.poses_t + i];
+            for (int i = gtid; i < w.Np * 3; i += gthreads) D[w.pts + i] = D[w.pts_t + i];
+            for (int i = gtid; i < w.E * 2; i += gthreads) D[w.err + i] = D[w.err_t + i];
         } else {
             lambda *= ni;
             ni *= 2;
@@ -1019,12 +1200,12 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
         qmax++;
         BA_STAMP(9)
         if (debug > 1 && tid == 0)
-            printf("[dev] win %d trial %d ok %d pcg %d cur %.10e temp %.10e rho %.6e lambda %.6e\n", (int)blockIdx.x, qmax,
+            printf("[dev] win %d trial %d ok %d pcg %d cur %.10e temp %.10e rho %.6e lambda %.6e\n", win, qmax,
                    (int)ok2, it, currentChi, tempChi, rho, lambda);
         __syncthreads();
     } while (rho < 0 && qmax < 10);
 
-    if (tid == 0) {
+    if (lead && tid == 0) {
         st[ST_LAMBDA] = lambda;
         st[ST_NI] = ni;
         st[ST_CHI] = currentChi;
@@ -1070,117 +1251,34 @@ __global__ __launch_bounds__(BA_T) void k_ba_classify(BABufs bufs, int drop_robu
 /* host staging of one window before concatenation; kept in the solver so that a steady stream of similar batches
  * re-uses the vectors' capacity (allocating and freeing ~2 MB per window per call cost more than the staging) */
 struct BAPiece {
-    std::vector<double> D;
+    std::vector<double> O, D; /* outputs (poses, points, LM state) and inputs (observations, information) */
     std::vector<int32_t> I;
     std::vector<uint8_t> B;
     size_t scratch = 0;
     int rc = 0;
 };
 
-struct BASolver {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    int max_cams, max_points, max_obs, max_batch;
-    double *dD = nullptr;
-    int32_t *dI = nullptr;
-    uint8_t *dB = nullptr;
-    BAWin *dW = nullptr;
-    size_t capD = 0, capI = 0, capB = 0, capW = 0;
-    /* pinned host staging (H2D from pageable memory runs at a fraction of the PCIe rate) */
-    double *pD = nullptr;
-    int32_t *pI = nullptr;
-    uint8_t *pB = nullptr;
-    size_t pcapD = 0, pcapI = 0, pcapB = 0;
-    std::vector<BAPiece> pieces;
-    double pcg_tol2 = 1e-26; /* relative M^-1-norm of the residual, squared */
-    int solver = 1;          /* 1 = dense blocked Cholesky (MFMA f64), 0 = PCG (ORBSLAM_AMD_BA_SOLVER=pcg) */
-};
-
-extern "C" int ba_create(int max_cams, int max_points, int max_obs, int max_batch, int device_id, BASolver **out) {
-    if (!out || max_cams <= 0 || max_points <= 0 || max_obs <= 0 || max_batch <= 0) return ORB_E_INVALID;
-    if (max_cams * 6 > BA_MAX_N) {
-        b_err = "ba_create: more than 256 free cameras per window are not supported";
-        return ORB_E_INVALID;
-    }
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return ORB_E_NO_DEVICE;
-    BCHK(hipSetDevice(device_id));
-    BASolver *s = new BASolver();
-    s->device = device_id;
-    s->max_cams = max_cams;
-    s->max_points = max_points;
-    s->max_obs = max_obs;
-    s->max_batch = max_batch;
-    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
-        delete s;
-        return ORB_E_HIP;
-    }
-    const char *tol = getenv("ORBSLAM_AMD_PCG_TOL");
-    if (tol) s->pcg_tol2 = atof(tol) * atof(tol);
-    if (getenv("ORBSLAM_AMD_CHOL_SCALAR")) {
-        int one = atoi(getenv("ORBSLAM_AMD_CHOL_SCALAR"));
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_chol_scalar), &one, sizeof(int));
-    }
-    const char *sv = getenv("ORBSLAM_AMD_BA_SOLVER");
-    if (sv && !strcmp(sv, "pcg")) s->solver = 0;
-    *out = s;
-    return ORB_OK;
-}
-
-extern "C" void ba_destroy(BASolver *s) {
-    if (!s) return;
-    (void)hipSetDevice(s->device);
-    if (s->stream) (void)hipStreamSynchronize(s->stream);
-    (void)hipFree(s->dD);
-    (void)hipFree(s->dI);
-    (void)hipFree(s->dB);
-    (void)hipFree(s->dW);
-    if (s->pD) (void)hipHostFree(s->pD);
-    if (s->pI) (void)hipHostFree(s->pI);
-    if (s->pB) (void)hipHostFree(s->pB);
-    if (s->stream) (void)hipStreamDestroy(s->stream);
-    delete s;
-}
-
-template <typename T> static int ba_grow(T *&p, size_t &cap, size_t need) {
-    if (need <= cap && p) return ORB_OK;
-    if (p) BCHK(hipFree(p));
-    p = nullptr;
-    cap = 0;
-    BCHK(hipMalloc((void **)&p, std::max<size_t>(need * sizeof(T), 256)));
-    cap = need;
-    return ORB_OK;
-}
-
-template <typename T> static int ba_grow_pinned(T *&p, size_t &cap, size_t need) {
-    if (need <= cap && p) return ORB_OK;
-    if (p) BCHK(hipHostFree(p));
-    p = nullptr;
-    cap = 0;
-    need += need / 4; /* head-room: batches of similar windows do not re-allocate */
-    BCHK(hipHostMalloc((void **)&p, std::max<size_t>(need * sizeof(T), 256)));
-    cap = need;
-    return ORB_OK;
-}
-
 struct HostWin {
     BAWin w;
     std::vector<int> perm; /* sorted edge -> caller's edge index */
 };
-/* fields of BAWin that are device-only scratch: their offsets are relative to the scratch base until
- * ba_solve_batch adds the size of the staged (uploaded) region */
-static int64_t BAWin::*const kInputDFields[] = {&BAWin::poses, &BAWin::pts, &BAWin::obs, &BAWin::info, &BAWin::st};
+/* Layout of a batch in the double buffer: [ outputs of every window | inputs of every window | scratch ].  The
+ * output region (poses, points, LM state) is what comes back, as ONE download; inputs only go up; scratch never
+ * crosses PCIe.  Until ba_stage() concatenates the windows, offsets are relative to the window's own piece. */
+static int64_t BAWin::*const kOutDFields[] = {&BAWin::poses, &BAWin::pts, &BAWin::st};
+static int64_t BAWin::*const kInDFields[] = {&BAWin::obs, &BAWin::info};
 static int64_t BAWin::*const kIntFields[] = {&BAWin::cam,     &BAWin::pt,      &BAWin::pt_start, &BAWin::cam_start,
                                              &BAWin::cam_edges, &BAWin::slot,  &BAWin::blk_row,  &BAWin::blk_col,
-                                             &BAWin::blk_diag, &BAWin::blk_mirror, &BAWin::blk_upper, &BAWin::blk_rowid, &BAWin::con_start, &BAWin::con_e1, &BAWin::con_e2, &BAWin::ch_first, &BAWin::ch_last};
+                                             &BAWin::blk_diag, &BAWin::blk_mirror, &BAWin::blk_upper, &BAWin::blk_rowid, &BAWin::con_start, &BAWin::con_e1, &BAWin::con_e2, &BAWin::ch_first, &BAWin::ch_last, &BAWin::gbar};
 static int64_t BAWin::*const kScratchFields[] = {&BAWin::poses_t, &BAWin::pts_t, &BAWin::err, &BAWin::err_t, &BAWin::W,
                                                  &BAWin::Y,       &BAWin::Hpp,   &BAWin::bp,  &BAWin::Hll,   &BAWin::bl,
                                                  &BAWin::Dinv,    &BAWin::S,     &BAWin::g,   &BAWin::Minv,  &BAWin::x,
-                                                 &BAWin::xl,      &BAWin::A,     &BAWin::Linv};
+                                                 &BAWin::xl,      &BAWin::A,     &BAWin::Linv, &BAWin::gred,  &BAWin::pcgv};
+#define BA_CHOL_LDS_BYTES (128 * 1024) /* dynamic LDS the blocked Cholesky may take beside the static 25 KB */
 
 /* lay one problem out in the host staging vectors; returns error code */
-static int stage_problem(const BAProblem *p, std::vector<double> &hD, size_t &scratchD, std::vector<int32_t> &hI,
-                         std::vector<uint8_t> &hB, HostWin &hw) {
+static int stage_problem(const BAProblem *p, std::vector<double> &hO, std::vector<double> &hD, size_t &scratchD,
+                         std::vector<int32_t> &hI, std::vector<uint8_t> &hB, HostWin &hw) {
     if (!p || p->n_cams <= 0 || p->n_points < 0 || p->n_obs < 0 || !p->poses || !p->fixed ||
         (p->n_points && !p->points) || (p->n_obs && (!p->obs || !p->cam_idx || !p->pt_idx || !p->inv_sigma2)) ||
         p->n_rounds < 1 || p->n_rounds > 4)
@@ -1213,7 +1311,6 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hD, size_t &sc
         }
     const int Ncf = (int)slot2cam.size();
     w.Ncf = Ncf;
-    if (Ncf * 6 > BA_MAX_N) return ORB_E_CAPACITY;
     /* camera edge lists (sorted-edge indices) */
     std::vector<int> cstart(Nc + 1, 0), cedges(E);
     for (int k = 0; k < E; k++) cstart[p->cam_idx[hw.perm[k]] + 1]++;
@@ -1277,7 +1374,12 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hD, size_t &sc
             }
     }
     /* ---- lay out ---- */
-    auto allocD = [&](size_t n) {
+    auto allocO = [&](size_t n) { /* outputs: downloaded */
+        size_t o = hO.size();
+        hO.resize(o + ((n + 1) & ~(size_t)1), 0.0);
+        return (int64_t)o;
+    };
+    auto allocD = [&](size_t n) { /* inputs: uploaded only */
         size_t o = hD.size();
         hD.resize(o + ((n + 1) & ~(size_t)1), 0.0);
         return (int64_t)o;
@@ -1292,9 +1394,9 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hD, size_t &sc
         hI.resize(o + n, 0);
         return (int64_t)o;
     };
-    w.poses = allocD((size_t)Nc * 7);
+    w.poses = allocO((size_t)Nc * 7);
     w.poses_t = allocS((size_t)Nc * 7);
-    w.pts = allocD((size_t)Np * 3);
+    w.pts = allocO((size_t)Np * 3);
     w.pts_t = allocS((size_t)Np * 3);
     w.obs = allocD((size_t)E * 2);
     w.info = allocD(E);
@@ -1312,22 +1414,19 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hD, size_t &sc
     w.Minv = allocS((size_t)Ncf * 36);
     w.x = allocS((size_t)Ncf * 6);
     w.xl = allocS(2);
-    {
-        const size_t np = ((size_t)Ncf * 6 + 15) & ~(size_t)15;
-        w.A = allocS(np * np);
-        w.Linv = allocS((np / 16) * 256);
-    }
-    w.st = allocD(ST_COUNT);
+    w.gred = allocS(4 * BA_GMAX);
+    w.pcgv = Ncf * 6 > BA_MAX_N ? allocS((size_t)5 * Ncf * 6) : 0; /* PCG vectors of a system too large for the LDS arrays */
+    w.st = allocO(ST_COUNT);
     for (int c = 0; c < Nc; c++) {
         double q[4] = {p->poses[c * 7], p->poses[c * 7 + 1], p->poses[c * 7 + 2], p->poses[c * 7 + 3]};
         if (q[0] < 0) { /* SE3Quat ctor: normalizeRotation */
             q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3];
         }
         const double nrm = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-        for (int i = 0; i < 4; i++) hD[w.poses + c * 7 + i] = q[i] / nrm;
-        for (int i = 0; i < 3; i++) hD[w.poses + c * 7 + 4 + i] = p->poses[c * 7 + 4 + i];
+        for (int i = 0; i < 4; i++) hO[w.poses + c * 7 + i] = q[i] / nrm;
+        for (int i = 0; i < 3; i++) hO[w.poses + c * 7 + 4 + i] = p->poses[c * 7 + 4 + i];
     }
-    for (int i = 0; i < Np * 3; i++) hD[w.pts + i] = p->points[i];
+    for (int i = 0; i < Np * 3; i++) hO[w.pts + i] = p->points[i];
     for (int k = 0; k < E; k++) {
         const int e = hw.perm[k];
         hD[w.obs + 2 * k] = p->obs[2 * e];
@@ -1382,6 +1481,16 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hD, size_t &sc
         int maxm = 1;
         for (int k = 0; k < nbt; k++) maxm = std::max(maxm, last[k] - k);
         w.ch_pm = maxm * 16;
+        /* the dense matrix of the blocked Cholesky exists only where its LDS panel fits; a window that is both large
+           and nearly dense is solved by PCG on the block-sparse S and needs no np x np storage */
+        const size_t np = ((size_t)Ncf * 6 + 15) & ~(size_t)15;
+        if (((size_t)w.ch_pm * 17 + 2 * 16 * 17 + np) * 8 <= BA_CHOL_LDS_BYTES) {
+            w.A = allocS(np * np);
+            w.Linv = allocS((np / 16) * 256);
+        } else {
+            w.ch_pm = -1; /* marks "no Cholesky" for the kernel and the launch code */
+            w.A = w.Linv = 0;
+        }
         w.ch_first = allocI(std::max(nbt, 1));
         w.ch_last = allocI(std::max(nbt, 1));
         for (int t = 0; t < nbt; t++) {
@@ -1405,19 +1514,185 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hD, size_t &sc
         hI[w.con_e1 + i] = ce1[i];
         hI[w.con_e2 + i] = ce2[i];
     }
+    w.gbar = allocI(2);
     w.flags = (int64_t)hB.size();
     hB.resize(hB.size() + ((E + 15) & ~15), 0);
     for (int k = 0; k < E; k++) hB[w.flags + k] = (uint8_t)(1 | (p->huber_delta > 0 ? 2 : 0));
     return ORB_OK;
 }
 
-extern "C" int ba_solve_batch(BASolver *s, const BAProblem *probs, BAResult *res, int nwin) {
-    if (!s || !probs || !res || nwin <= 0) return ORB_E_INVALID;
-    if (nwin > s->max_batch) return ORB_E_CAPACITY;
-    BCHK(hipSetDevice(s->device));
+
+/* One batch in flight: its own pinned staging and device buffers, so that the host side of batch k+1 (index sorting,
+ * contribution lists, concatenation, upload) and the download / unpacking of batch k-1 overlap the kernels of
+ * batch k.  ba_solve_batch uses slot 0 synchronously; ba_submit_batch / ba_wait alternate between the two. */
+struct BAJob {
+    double *pD = nullptr; /* pinned */
+    int32_t *pI = nullptr;
+    uint8_t *pB = nullptr;
+    size_t pcapD = 0, pcapI = 0, pcapB = 0;
+    double *dD = nullptr; /* device */
+    int32_t *dI = nullptr;
+    uint8_t *dB = nullptr;
+    BAWin *dW = nullptr;
+    size_t capD = 0, capI = 0, capB = 0, capW = 0;
+    std::vector<HostWin> hw;
+    std::vector<BAWin> wins;
+    size_t nOut = 0, nIn = 0, nI = 0, nB = 0, scratchD = 0; /* element counts */
+    const BAProblem *probs = nullptr;
+    BAResult *res = nullptr;
+    int nwin = 0;
+    bool pending = false;
+    hipEvent_t uploaded = nullptr, solved = nullptr, downloaded = nullptr;
+    std::vector<hipEvent_t> prof_ev; /* pairs around every k_ba_iteration launch (profiling only) */
+    int prof_launches = 0;
+    int team = 1;
+    double t_start = 0, t_staged = 0, t_enqueued = 0;
+};
+
+struct BASolver {
+    int device = 0;
+    hipStream_t stream = nullptr;   /* kernels */
+    hipStream_t copy_in = nullptr;  /* uploads of the NEXT batch */
+    hipStream_t copy_out = nullptr; /* downloads of the PREVIOUS batch */
+    int max_cams, max_points, max_obs, max_batch;
+    int cu_count = 256;
+    BAJob job[2];
+    int next_slot = 0, oldest_slot = 0, in_flight = 0;
+    std::vector<BAPiece> pieces;
+    /* Optimizer::PoseOptimization has its own small buffers: Tracking may call it while a BA batch is in flight */
+    double *poD = nullptr, *ppD = nullptr;
+    int32_t *poI = nullptr, *ppI = nullptr;
+    uint8_t *poB = nullptr, *ppB = nullptr;
+    size_t pocapD = 0, pocapI = 0, pocapB = 0, ppcapD = 0, ppcapI = 0, ppcapB = 0;
+    double pcg_tol2 = 1e-26; /* relative M^-1-norm of the residual, squared */
+    int solver = 1;          /* 1 = dense blocked Cholesky (MFMA f64), 0 = PCG (ORBSLAM_AMD_BA_SOLVER=pcg) */
+    int force_team = 0;      /* ORBSLAM_AMD_BA_TEAM: workgroups per window (0 = choose) */
+    bool profiling = false;
+    float last_iter_ms = 0.f; /* average k_ba_iteration launch of the last finished batch */
+    int last_iter_launches = 0, last_team = 1;
+};
+
+extern "C" int ba_create(int max_cams, int max_points, int max_obs, int max_batch, int device_id, BASolver **out) {
+    if (!out || max_cams <= 0 || max_points <= 0 || max_obs <= 0 || max_batch <= 0) return ORB_E_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return ORB_E_NO_DEVICE;
+    BCHK(hipSetDevice(device_id));
+    BASolver *s = new BASolver();
+    s->device = device_id;
+    s->max_cams = max_cams;
+    s->max_points = max_points;
+    s->max_obs = max_obs;
+    s->max_batch = max_batch;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) s->cu_count = prop.multiProcessorCount;
+    bool ok = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&s->copy_in, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&s->copy_out, hipStreamNonBlocking) == hipSuccess;
+    for (int j = 0; j < 2 && ok; j++)
+        ok = hipEventCreateWithFlags(&s->job[j].uploaded, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&s->job[j].solved, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&s->job[j].downloaded, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        b_err = "ba_create: stream / event creation failed";
+        ba_destroy(s);
+        return ORB_E_HIP;
+    }
+    const char *tol = getenv("ORBSLAM_AMD_PCG_TOL");
+    if (tol) s->pcg_tol2 = atof(tol) * atof(tol);
+    if (getenv("ORBSLAM_AMD_CHOL_SCALAR")) {
+        int one = atoi(getenv("ORBSLAM_AMD_CHOL_SCALAR"));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_chol_scalar), &one, sizeof(int));
+    }
+    const char *sv = getenv("ORBSLAM_AMD_BA_SOLVER");
+    if (sv && !strcmp(sv, "pcg")) s->solver = 0;
+    if (getenv("ORBSLAM_AMD_BA_TEAM")) s->force_team = atoi(getenv("ORBSLAM_AMD_BA_TEAM"));
+    *out = s;
+    return ORB_OK;
+}
+
+extern "C" void ba_destroy(BASolver *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->copy_in) (void)hipStreamSynchronize(s->copy_in);
+    if (s->copy_out) (void)hipStreamSynchronize(s->copy_out);
+    for (BAJob &j : s->job) {
+        (void)hipFree(j.dD);
+        (void)hipFree(j.dI);
+        (void)hipFree(j.dB);
+        (void)hipFree(j.dW);
+        if (j.pD) (void)hipHostFree(j.pD);
+        if (j.pI) (void)hipHostFree(j.pI);
+        if (j.pB) (void)hipHostFree(j.pB);
+        if (j.uploaded) (void)hipEventDestroy(j.uploaded);
+        if (j.solved) (void)hipEventDestroy(j.solved);
+        if (j.downloaded) (void)hipEventDestroy(j.downloaded);
+        for (hipEvent_t e : j.prof_ev) (void)hipEventDestroy(e);
+    }
+    (void)hipFree(s->poD);
+    (void)hipFree(s->poI);
+    (void)hipFree(s->poB);
+    if (s->ppD) (void)hipHostFree(s->ppD);
+    if (s->ppI) (void)hipHostFree(s->ppI);
+    if (s->ppB) (void)hipHostFree(s->ppB);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    if (s->copy_in) (void)hipStreamDestroy(s->copy_in);
+    if (s->copy_out) (void)hipStreamDestroy(s->copy_out);
+    delete s;
+}
+
+extern "C" int ba_set_profiling(BASolver *s, int enable) {
+    if (!s) return ORB_E_INVALID;
+    s->profiling = enable != 0;
+    return ORB_OK;
+}
+
+extern "C" int ba_get_iteration_ms(BASolver *s, float *avg_ms, int32_t *n_launches, int32_t *team) {
+    if (!s) return ORB_E_INVALID;
+    if (avg_ms) *avg_ms = s->last_iter_ms;
+    if (n_launches) *n_launches = s->last_iter_launches;
+    if (team) *team = s->last_team;
+    return ORB_OK;
+}
+
+template <typename T> static int ba_grow(T *&p, size_t &cap, size_t need) {
+    if (need <= cap && p) return ORB_OK;
+    if (p) BCHK(hipFree(p));
+    p = nullptr;
+    cap = 0;
+    BCHK(hipMalloc((void **)&p, std::max<size_t>(need * sizeof(T), 256)));
+    cap = need;
+    return ORB_OK;
+}
+
+template <typename T> static int ba_grow_pinned(T *&p, size_t &cap, size_t need) {
+    if (need <= cap && p) return ORB_OK;
+    if (p) BCHK(hipHostFree(p));
+    p = nullptr;
+    cap = 0;
+    need += need / 4; /* head-room: batches of similar windows do not re-allocate */
+    BCHK(hipHostMalloc((void **)&p, std::max<size_t>(need * sizeof(T), 256)));
+    cap = need;
+    return ORB_OK;
+}
+
+static double ba_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+template <class F> static void ba_parallel(int nthr, F &&f) {
+    if (nthr <= 1) {
+        f(0);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nthr; t++) pool.emplace_back(f, t);
+    for (auto &th : pool) th.join();
+}
+
+/* host side of a batch: per-window staging on a pool of host threads (index sorting and the contribution lists are
+ * O(sum k^2) per window), then concatenation into the job's pinned buffers */
+static int ba_stage(BASolver *s, BAJob &J, const BAProblem *probs, BAResult *res, int nwin) {
     const BAProblem &P0 = probs[0];
     for (int i = 0; i < nwin; i++) {
-        if (probs[i].stop && *probs[i].stop) return ORB_E_STOPPED;
         if (probs[i].n_rounds != P0.n_rounds || memcmp(probs[i].rounds, P0.rounds, sizeof(P0.rounds)) ||
             probs[i].drop_robust_after != P0.drop_robust_after) {
             b_err = "ba_solve_batch: all windows of a batch must share one iteration schedule";
@@ -1425,116 +1700,142 @@ extern "C" int ba_solve_batch(BASolver *s, const BAProblem *probs, BAResult *res
         }
         if (!res[i].poses || (probs[i].n_points && !res[i].points)) return ORB_E_INVALID;
     }
-    size_t hD_n = 0, hI_n = 0, hB_n = 0; /* element counts of the pinned staging buffers s->pD / pI / pB */
-    const bool prof = getenv("ORBSLAM_AMD_BA_PROFILE") != nullptr;
-    auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t_start = tnow();
-    std::vector<HostWin> hw(nwin);
-    std::vector<BAWin> wins(nwin);
-    size_t scratchD = 0;
-    {
-        /* every window is staged into its own vectors on a pool of host threads (index sorting and the
-           contribution lists are O(sum k^2) per window), then the pieces are concatenated */
-        typedef BAPiece Piece;
-        if ((int)s->pieces.size() < nwin) s->pieces.resize(nwin);
-        std::vector<BAPiece> &pieces = s->pieces;
-        for (int i = 0; i < nwin; i++) {
-            pieces[i].D.clear();
-            pieces[i].I.clear();
-            pieces[i].B.clear();
-            pieces[i].scratch = 0;
-            pieces[i].rc = 0;
+    J.t_start = ba_now();
+    J.probs = probs;
+    J.res = res;
+    J.nwin = nwin;
+    J.hw.resize(nwin);
+    J.wins.resize(nwin);
+    if ((int)s->pieces.size() < nwin) s->pieces.resize(nwin);
+    std::vector<BAPiece> &pieces = s->pieces;
+    const int nthr = std::max(1, std::min<int>(nwin, std::min<int>(16, (int)std::thread::hardware_concurrency())));
+    ba_parallel(nthr, [&](int t) {
+        for (int i = t; i < nwin; i += nthr) {
+            BAPiece &pc = pieces[i];
+            pc.O.clear();
+            pc.D.clear();
+            pc.I.clear();
+            pc.B.clear();
+            pc.scratch = 0;
+            pc.rc = stage_problem(&probs[i], pc.O, pc.D, pc.scratch, pc.I, pc.B, J.hw[i]);
         }
-        const int nthr = std::max(1, std::min<int>(nwin, std::min<int>(16, (int)std::thread::hardware_concurrency())));
-        auto work = [&](int t) {
-            for (int i = t; i < nwin; i += nthr)
-                pieces[i].rc = stage_problem(&probs[i], pieces[i].D, pieces[i].scratch, pieces[i].I, pieces[i].B, hw[i]);
-        };
-        if (nthr == 1)
-            work(0);
-        else {
-            std::vector<std::thread> pool;
-            for (int t = 0; t < nthr; t++) pool.emplace_back(work, t);
-            for (auto &th : pool) th.join();
-        }
-        size_t nD = 0, nI = 0, nB = 0;
-        std::vector<size_t> oDs(nwin), oIs(nwin), oBs(nwin);
-        for (int i = 0; i < nwin; i++) {
-            if (pieces[i].rc) return pieces[i].rc;
-            oDs[i] = nD;
-            oIs[i] = nI;
-            oBs[i] = nB;
-            nD += pieces[i].D.size();
-            nI += pieces[i].I.size();
-            nB += pieces[i].B.size();
-        }
-        int rcp;
-        if ((rcp = ba_grow_pinned(s->pD, s->pcapD, nD))) return rcp;
-        if ((rcp = ba_grow_pinned(s->pI, s->pcapI, std::max<size_t>(nI, 1)))) return rcp;
-        if ((rcp = ba_grow_pinned(s->pB, s->pcapB, std::max<size_t>(nB, 1)))) return rcp;
-        hD_n = nD;
-        hI_n = nI;
-        hB_n = nB;
-        auto merge = [&](int t) {
-            for (int i = t; i < nwin; i += nthr) {
-                Piece &pc = pieces[i];
-                memcpy(s->pD + oDs[i], pc.D.data(), pc.D.size() * sizeof(double));
-                memcpy(s->pI + oIs[i], pc.I.data(), pc.I.size() * sizeof(int32_t));
-                memcpy(s->pB + oBs[i], pc.B.data(), pc.B.size());
-            }
-        };
-        if (nthr == 1)
-            merge(0);
-        else {
-            std::vector<std::thread> pool;
-            for (int t = 0; t < nthr; t++) pool.emplace_back(merge, t);
-            for (auto &th : pool) th.join();
-        }
-        for (int i = 0; i < nwin; i++) {
-            for (auto f : kInputDFields) hw[i].w.*f += (int64_t)oDs[i];
-            for (auto f : kIntFields) hw[i].w.*f += (int64_t)oIs[i];
-            hw[i].w.flags += (int64_t)oBs[i];
-            for (auto f : kScratchFields) hw[i].w.*f += (int64_t)(nD + scratchD);
-            scratchD += pieces[i].scratch;
-            wins[i] = hw[i].w;
-        }
+    });
+    size_t nO = 0, nD = 0, nI = 0, nB = 0;
+    std::vector<size_t> oO(nwin), oD(nwin), oI(nwin), oB(nwin);
+    for (int i = 0; i < nwin; i++) {
+        if (pieces[i].rc) return pieces[i].rc;
+        oO[i] = nO;
+        oD[i] = nD;
+        oI[i] = nI;
+        oB[i] = nB;
+        nO += pieces[i].O.size();
+        nD += pieces[i].D.size();
+        nI += pieces[i].I.size();
+        nB += pieces[i].B.size();
     }
     int rc;
-    if ((rc = ba_grow(s->dD, s->capD, hD_n + scratchD))) return rc;
-    if ((rc = ba_grow(s->dI, s->capI, std::max<size_t>(hI_n, 1)))) return rc;
-    if ((rc = ba_grow(s->dB, s->capB, std::max<size_t>(hB_n, 1)))) return rc;
-    if ((rc = ba_grow(s->dW, s->capW, (size_t)nwin))) return rc;
-    BCHK(hipMemcpyAsync(s->dD, s->pD, hD_n * 8, hipMemcpyHostToDevice, s->stream));
-    if (hI_n) BCHK(hipMemcpyAsync(s->dI, s->pI, hI_n * 4, hipMemcpyHostToDevice, s->stream));
-    if (hB_n) BCHK(hipMemcpyAsync(s->dB, s->pB, hB_n, hipMemcpyHostToDevice, s->stream));
-    BCHK(hipMemcpyAsync(s->dW, wins.data(), (size_t)nwin * sizeof(BAWin), hipMemcpyHostToDevice, s->stream));
-    BABufs bufs{s->dD, s->dI, s->dB, s->dW};
-    if (prof) BCHK(hipStreamSynchronize(s->stream));
-    const double t_staged = tnow();
+    if ((rc = ba_grow_pinned(J.pD, J.pcapD, nO + nD))) return rc;
+    if ((rc = ba_grow_pinned(J.pI, J.pcapI, std::max<size_t>(nI, 1)))) return rc;
+    if ((rc = ba_grow_pinned(J.pB, J.pcapB, std::max<size_t>(nB, 1)))) return rc;
+    J.nOut = nO;
+    J.nIn = nD;
+    J.nI = nI;
+    J.nB = nB;
+    ba_parallel(nthr, [&](int t) {
+        for (int i = t; i < nwin; i += nthr) {
+            BAPiece &pc = pieces[i];
+            memcpy(J.pD + oO[i], pc.O.data(), pc.O.size() * sizeof(double));
+            memcpy(J.pD + nO + oD[i], pc.D.data(), pc.D.size() * sizeof(double));
+            memcpy(J.pI + oI[i], pc.I.data(), pc.I.size() * sizeof(int32_t));
+            memcpy(J.pB + oB[i], pc.B.data(), pc.B.size());
+        }
+    });
+    size_t scratchD = 0;
+    for (int i = 0; i < nwin; i++) {
+        BAWin &w = J.hw[i].w;
+        for (auto f : kOutDFields) w.*f += (int64_t)oO[i];
+        for (auto f : kInDFields) w.*f += (int64_t)(nO + oD[i]);
+        for (auto f : kIntFields) w.*f += (int64_t)oI[i];
+        w.flags += (int64_t)oB[i];
+        for (auto f : kScratchFields) w.*f += (int64_t)(nO + nD + scratchD);
+        scratchD += pieces[i].scratch;
+        J.wins[i] = w;
+    }
+    J.scratchD = scratchD;
+    J.t_staged = ba_now();
+    return ORB_OK;
+}
+
+/* workgroups per window: as many as fit co-resident AND as the window's size can feed (a team member needs a few
+ * hundred edges per phase to be worth its barrier) */
+static int ba_choose_team(BASolver *s, const BAJob &J, size_t dyn_bytes) {
+    int occ = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_ba_iteration, BA_T, dyn_bytes) != hipSuccess || occ < 1) occ = 1;
+    const int resident = s->cu_count * occ;
+    int maxE = 0;
+    for (int i = 0; i < J.nwin; i++) maxE = std::max(maxE, J.wins[i].E);
+    int want = s->force_team > 0 ? s->force_team : std::max(1, maxE / 768);
+    int G = 1;
+    while (G * 2 <= BA_GMAX && G * 2 <= want && (long)J.nwin * (G * 2) <= resident) G *= 2;
+    return G;
+}
+
+/* device side of a batch: upload on the copy-in stream, LM iterations on the compute stream, download of the output
+ * region on the copy-out stream; returns without waiting unless a stop flag has to be polled between iterations */
+static int ba_enqueue(BASolver *s, BAJob &J) {
+    const int nwin = J.nwin;
+    const BAProblem *probs = J.probs;
+    const BAProblem &P0 = probs[0];
+    const bool prof = getenv("ORBSLAM_AMD_BA_PROFILE") != nullptr;
+    int rc;
+    if ((rc = ba_grow(J.dD, J.capD, J.nOut + J.nIn + J.scratchD))) return rc;
+    if ((rc = ba_grow(J.dI, J.capI, std::max<size_t>(J.nI, 1)))) return rc;
+    if ((rc = ba_grow(J.dB, J.capB, std::max<size_t>(J.nB, 1)))) return rc;
+    if ((rc = ba_grow(J.dW, J.capW, (size_t)nwin))) return rc;
+    BCHK(hipMemcpyAsync(J.dD, J.pD, (J.nOut + J.nIn) * 8, hipMemcpyHostToDevice, s->copy_in));
+    if (J.nI) BCHK(hipMemcpyAsync(J.dI, J.pI, J.nI * 4, hipMemcpyHostToDevice, s->copy_in));
+    if (J.nB) BCHK(hipMemcpyAsync(J.dB, J.pB, J.nB, hipMemcpyHostToDevice, s->copy_in));
+    BCHK(hipMemcpyAsync(J.dW, J.wins.data(), (size_t)nwin * sizeof(BAWin), hipMemcpyHostToDevice, s->copy_in));
+    BCHK(hipEventRecord(J.uploaded, s->copy_in));
+    BCHK(hipStreamWaitEvent(s->stream, J.uploaded, 0));
+    BABufs bufs{J.dD, J.dI, J.dB, J.dW};
+    bool any_stop_ptr = false;
+    for (int i = 0; i < nwin; i++) any_stop_ptr |= probs[i].stop != nullptr;
     auto stopped = [&]() {
         for (int i = 0; i < nwin; i++)
             if (probs[i].stop && *probs[i].stop) return true;
         return false;
     };
     int maxn = 0;
-    for (int i = 0; i < nwin; i++) maxn = std::max(maxn, wins[i].Ncf * 6);
+    for (int i = 0; i < nwin; i++) maxn = std::max(maxn, J.wins[i].Ncf * 6);
     int pcg_maxit = 6 * maxn + 100; /* CG needs > n steps in floating point when S is ill-conditioned */
     if (getenv("ORBSLAM_AMD_PCG_MAXIT")) pcg_maxit = atoi(getenv("ORBSLAM_AMD_PCG_MAXIT")); /* profiling only */
-    /* dynamic LDS of the Cholesky solver: panel + two 16x16 blocks + rhs, for the largest window of the batch */
+    /* dynamic LDS of the Cholesky solver: envelope-sized panel + two 16x16 blocks + rhs, for the largest window of the
+       batch that has a dense matrix at all (ch_pm > 0); the others take PCG inside the kernel */
     int dyn_doubles = 0;
     if (s->solver == 1) {
-        /* per window: envelope-sized panel + two 16x16 blocks + rhs; windows whose need exceeds 128 KB (a wide
-           envelope AND many cameras) fall back to PCG inside the kernel */
         for (int i = 0; i < nwin; i++) {
-            const size_t npw = ((size_t)wins[i].Ncf * 6 + 15) & ~(size_t)15;
-            const size_t need = (size_t)wins[i].ch_pm * 17 + 2 * 16 * 17 + npw;
-            if (need * 8 <= 128 * 1024) dyn_doubles = std::max(dyn_doubles, (int)need);
+            if (J.wins[i].ch_pm <= 0) continue;
+            const size_t npw = ((size_t)J.wins[i].Ncf * 6 + 15) & ~(size_t)15;
+            dyn_doubles = std::max(dyn_doubles, (int)((size_t)J.wins[i].ch_pm * 17 + 2 * 16 * 17 + npw));
         }
         static PerDeviceLdsLimit lim;
-        if (lim.raise((size_t)dyn_doubles * 8))
-            BCHK(hipFuncSetAttribute((const void *)k_ba_iteration, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     dyn_doubles * 8));
+        BCHK(lim.ensure((const void *)k_ba_iteration, (size_t)dyn_doubles * 8));
     }
+    const int G = ba_choose_team(s, J, (size_t)dyn_doubles * 8);
+    J.team = G;
+    const int debug = getenv("ORBSLAM_AMD_BA_DEBUG") ? 2 : (prof ? 1 : 0);
+    int total_its = 0;
+    for (int r = 0; r < P0.n_rounds; r++) total_its += P0.rounds[r];
+    if (s->profiling) {
+        while ((int)J.prof_ev.size() < 2 * total_its) {
+            hipEvent_t e;
+            BCHK(hipEventCreate(&e));
+            J.prof_ev.push_back(e);
+        }
+    }
+    J.prof_launches = 0;
+    int seq = 0;
     bool halted = false;
     for (int round = 0; round < P0.n_rounds && !halted; round++) {
         for (int it = 0; it < P0.rounds[round]; it++) {
@@ -1542,13 +1843,23 @@ extern "C" int ba_solve_batch(BASolver *s, const BAProblem *probs, BAResult *res
                 halted = true;
                 break;
             }
-            hipLaunchKernelGGL(k_ba_iteration, dim3(nwin), dim3(BA_T), (size_t)dyn_doubles * 8, s->stream, bufs,
-                               it == 0 ? 1 : 0, s->pcg_tol2, pcg_maxit, getenv("ORBSLAM_AMD_BA_DEBUG") ? 2 : (prof ? 1 : 0),
-                               s->solver, dyn_doubles);
-            BCHK(hipGetLastError());
+            if (s->profiling) BCHK(hipEventRecord(J.prof_ev[2 * J.prof_launches], s->stream));
+            int first = it == 0 ? 1 : 0, solver = s->solver, g = G, sq = seq++;
+            double tol2 = s->pcg_tol2;
+            int dbg = debug;
+            if (G > 1) {
+                /* a team needs all its workgroups resident at once: cooperative launch */
+                void *args[] = {&bufs, &first, &tol2, &pcg_maxit, &dbg, &solver, &dyn_doubles, &g, &sq};
+                BCHK(hipLaunchCooperativeKernel((const void *)k_ba_iteration, dim3(nwin * G), dim3(BA_T), args,
+                                                (size_t)dyn_doubles * 8, s->stream));
+            } else {
+                hipLaunchKernelGGL(k_ba_iteration, dim3(nwin), dim3(BA_T), (size_t)dyn_doubles * 8, s->stream, bufs, first, tol2,
+                                   pcg_maxit, dbg, solver, dyn_doubles, 1, sq);
+                BCHK(hipGetLastError());
+            }
+            if (s->profiling) BCHK(hipEventRecord(J.prof_ev[2 * J.prof_launches + 1], s->stream));
+            J.prof_launches++;
             /* the stop flag must be observed between iterations, as the reference's optimizer would */
-            bool any_stop_ptr = false;
-            for (int i = 0; i < nwin; i++) any_stop_ptr |= probs[i].stop != nullptr;
             if (any_stop_ptr) BCHK(hipStreamSynchronize(s->stream));
         }
         if (halted) break;
@@ -1561,62 +1872,113 @@ extern "C" int ba_solve_batch(BASolver *s, const BAProblem *probs, BAResult *res
     }
     hipLaunchKernelGGL(k_ba_classify, dim3(nwin), dim3(BA_T), 0, s->stream, bufs, 0, 1);
     BCHK(hipGetLastError());
-    if (prof) BCHK(hipStreamSynchronize(s->stream));
-    const double t_solved = tnow();
-    /* results */
-    if (nwin >= 16) {
-        /* large batch: ONE copy of the whole staged region (observations included) beats three small copies per
-           window -- ~10 us of launch cost each against 57 GB/s of PCIe */
-        BCHK(hipMemcpyAsync(s->pD, s->dD, hD_n * 8, hipMemcpyDeviceToHost, s->stream));
-    } else {
-        for (int i = 0; i < nwin; i++) { /* only poses, points and the LM state come back */
-            const BAWin &w = wins[i];
-            BCHK(hipMemcpyAsync(&s->pD[w.poses], s->dD + w.poses, (size_t)w.Nc * 7 * 8, hipMemcpyDeviceToHost, s->stream));
-            if (w.Np) BCHK(hipMemcpyAsync(&s->pD[w.pts], s->dD + w.pts, (size_t)w.Np * 3 * 8, hipMemcpyDeviceToHost, s->stream));
-            BCHK(hipMemcpyAsync(&s->pD[w.st], s->dD + w.st, (size_t)ST_COUNT * 8, hipMemcpyDeviceToHost, s->stream));
+    BCHK(hipEventRecord(J.solved, s->stream));
+    /* results: the output region only (poses, points, LM state of every window), plus the edge flags */
+    BCHK(hipStreamWaitEvent(s->copy_out, J.solved, 0));
+    BCHK(hipMemcpyAsync(J.pD, J.dD, J.nOut * 8, hipMemcpyDeviceToHost, s->copy_out));
+    bool want_flags = false;
+    for (int i = 0; i < nwin; i++) want_flags |= J.res[i].outlier != nullptr;
+    if (J.nB && want_flags) BCHK(hipMemcpyAsync(J.pB, J.dB, J.nB, hipMemcpyDeviceToHost, s->copy_out));
+    BCHK(hipEventRecord(J.downloaded, s->copy_out));
+    J.t_enqueued = ba_now();
+    J.pending = true;
+    return ORB_OK;
+}
+
+static int ba_finish(BASolver *s, BAJob &J) {
+    BCHK(hipEventSynchronize(J.downloaded));
+    J.pending = false;
+    const double t_done = ba_now();
+    const int nwin = J.nwin;
+    BAResult *res = J.res;
+    const int nt = std::max(1, std::min<int>(nwin / 8, std::min<int>(16, (int)std::thread::hardware_concurrency())));
+    ba_parallel(nt, [&](int t) {
+        for (int i = t; i < nwin; i += nt) {
+            const BAWin &w = J.wins[i];
+            memcpy(res[i].poses, &J.pD[w.poses], (size_t)w.Nc * 7 * 8);
+            if (w.Np) memcpy(res[i].points, &J.pD[w.pts], (size_t)w.Np * 3 * 8);
+            if (res[i].outlier)
+                for (int k = 0; k < w.E; k++) res[i].outlier[J.hw[i].perm[k]] = (J.pB[w.flags + k] & 1) ? 0 : 1;
+            res[i].chi2_initial = J.pD[w.st + ST_CHI0];
+            res[i].chi2_final = J.pD[w.st + ST_CHI];
+            res[i].iterations = (int)J.pD[w.st + ST_ITERS];
+            res[i].lin_solves = (int)J.pD[w.st + ST_SOLVES];
         }
-    }
-    if (hB_n) BCHK(hipMemcpyAsync(s->pB, s->dB, hB_n, hipMemcpyDeviceToHost, s->stream));
-    BCHK(hipStreamSynchronize(s->stream));
-    {
-        auto unpack = [&](int t, int nt) {
-            for (int i = t; i < nwin; i += nt) {
-                const BAWin &w = wins[i];
-                memcpy(res[i].poses, &s->pD[w.poses], (size_t)w.Nc * 7 * 8);
-                if (w.Np) memcpy(res[i].points, &s->pD[w.pts], (size_t)w.Np * 3 * 8);
-                if (res[i].outlier)
-                    for (int k = 0; k < w.E; k++) res[i].outlier[hw[i].perm[k]] = (s->pB[w.flags + k] & 1) ? 0 : 1;
-                res[i].chi2_initial = s->pD[w.st + ST_CHI0];
-                res[i].chi2_final = s->pD[w.st + ST_CHI];
-                res[i].iterations = (int)s->pD[w.st + ST_ITERS];
-                res[i].lin_solves = (int)s->pD[w.st + ST_SOLVES];
-            }
-        };
-        const int nt = std::max(1, std::min<int>(nwin / 8, std::min<int>(16, (int)std::thread::hardware_concurrency())));
-        if (nt == 1)
-            unpack(0, 1);
-        else {
-            std::vector<std::thread> pool;
-            for (int t = 0; t < nt; t++) pool.emplace_back(unpack, t, nt);
-            for (auto &th : pool) th.join();
+    });
+    s->last_team = J.team;
+    if (s->profiling && J.prof_launches > 0) {
+        double sum = 0;
+        for (int k = 0; k < J.prof_launches; k++) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, J.prof_ev[2 * k], J.prof_ev[2 * k + 1]) == hipSuccess) sum += ms;
         }
+        s->last_iter_ms = (float)(sum / J.prof_launches);
+        s->last_iter_launches = J.prof_launches;
     }
-    if (prof) {
+    if (getenv("ORBSLAM_AMD_BA_PROFILE")) {
         double pcg = 0;
-        for (int i = 0; i < nwin; i++) pcg += s->pD[wins[i].st + ST_PCG_ITERS];
-        fprintf(stderr, "[ba] %d windows: stage+upload %.2f ms, device %.2f ms, download %.2f ms, D %.1f MB, I %.1f MB, pcg its/window %.0f\n",
-                nwin, (t_staged - t_start) * 1e3, (t_solved - t_staged) * 1e3, (tnow() - t_solved) * 1e3,
-                (hD_n + scratchD) * 8e-6, hI_n * 4e-6, pcg / nwin);
+        for (int i = 0; i < nwin; i++) pcg += J.pD[J.wins[i].st + ST_PCG_ITERS];
+        fprintf(stderr, "[ba] %d windows x team %d: stage %.2f ms, enqueue %.2f ms, wait %.2f ms, unpack %.2f ms, up %.1f MB (D) + %.1f MB (I), down %.1f MB, scratch %.1f MB, pcg its/window %.0f\n",
+                nwin, J.team, (J.t_staged - J.t_start) * 1e3, (J.t_enqueued - J.t_staged) * 1e3, (t_done - J.t_enqueued) * 1e3,
+                (ba_now() - t_done) * 1e3, (J.nOut + J.nIn) * 8e-6, J.nI * 4e-6, J.nOut * 8e-6, J.scratchD * 8e-6, pcg / nwin);
         static const char *names[10] = {"chi2", "Hll+W", "Hpp", "Dinv+Y(+lambda0)", "Schur", "g+diag", "Minv", "PCG",
                                         "backsub+update", "trial chi2+decision"};
         fprintf(stderr, "[ba] window 0 phase ms:");
-        for (int k = 0; k < 10; k++) fprintf(stderr, " %s %.2f |", names[k], s->pD[wins[0].st + ST_T0 + k] * 1e-5);
+        for (int k = 0; k < 10; k++) fprintf(stderr, " %s %.2f |", names[k], J.pD[J.wins[0].st + ST_T0 + k] * 1e-5);
         fprintf(stderr, "\n");
     }
     return ORB_OK;
 }
 
+static int ba_check_batch(BASolver *s, const BAProblem *probs, BAResult *res, int nwin) {
+    if (!s || !probs || !res || nwin <= 0) return ORB_E_INVALID;
+    if (nwin > s->max_batch) return ORB_E_CAPACITY;
+    for (int i = 0; i < nwin; i++)
+        if (probs[i].stop && *probs[i].stop) return ORB_E_STOPPED;
+    return ORB_OK;
+}
+
+/* asynchronous pair: ba_submit_batch stages a batch and enqueues its device work, ba_wait returns the oldest
+ * submitted batch's results.  Two batches may be in flight; probs / res (and everything they point to) must stay
+ * valid until the matching ba_wait.  A batch that carries a stop flag is polled between iterations and therefore
+ * runs synchronously inside submit. */
+extern "C" int ba_submit_batch(BASolver *s, const BAProblem *probs, BAResult *res, int nwin) {
+    int rc = ba_check_batch(s, probs, res, nwin);
+    if (rc) return rc;
+    if (s->in_flight >= 2) {
+        b_err = "ba_submit_batch: two batches already in flight, call ba_wait first";
+        return ORB_E_BUSY;
+    }
+    BCHK(hipSetDevice(s->device));
+    BAJob &J = s->job[s->next_slot];
+    if ((rc = ba_stage(s, J, probs, res, nwin))) return rc;
+    if ((rc = ba_enqueue(s, J))) return rc;
+    s->next_slot ^= 1;
+    s->in_flight++;
+    return ORB_OK;
+}
+
+extern "C" int ba_wait(BASolver *s) {
+    if (!s) return ORB_E_INVALID;
+    if (s->in_flight <= 0) return ORB_OK;
+    BCHK(hipSetDevice(s->device));
+    BAJob &J = s->job[s->oldest_slot];
+    s->oldest_slot ^= 1;
+    s->in_flight--;
+    return ba_finish(s, J);
+}
+
+extern "C" int ba_solve_batch(BASolver *s, const BAProblem *probs, BAResult *res, int nwin) {
+    int rc = ba_check_batch(s, probs, res, nwin);
+    if (rc) return rc;
+    while (s->in_flight > 0)
+        if ((rc = ba_wait(s))) return rc;
+    if ((rc = ba_submit_batch(s, probs, res, nwin))) return rc;
+    return ba_wait(s);
+}
+
 extern "C" int ba_solve(BASolver *s, const BAProblem *p, BAResult *r) { return ba_solve_batch(s, p, r, 1); }
+
 
 /* ================================================================================================
  * Optimizer::PoseOptimization (reference src/Optimizer.cpp:131-261): one free SE3 vertex, n unary
@@ -1922,28 +2284,28 @@ extern "C" int ba_pose_optimization_batch(BASolver *s, double *poses, const doub
     BCHK(hipSetDevice(s->device));
     int rc;
     const size_t nd = (size_t)n_problems * 7 + (size_t)n * 6 + 8, nb = (size_t)n * 2 + 16;
-    if ((rc = ba_grow(s->dD, s->capD, nd))) return rc;
-    if ((rc = ba_grow(s->dB, s->capB, nb))) return rc;
-    if ((rc = ba_grow(s->dI, s->capI, (size_t)2 * n_problems + 4))) return rc;
-    double *d_pose = s->dD, *d_xw = d_pose + (((size_t)n_problems * 7 + 1) & ~(size_t)1), *d_obs = d_xw + (size_t)n * 3,
+    if ((rc = ba_grow(s->poD, s->pocapD, nd))) return rc;
+    if ((rc = ba_grow(s->poB, s->pocapB, nb))) return rc;
+    if ((rc = ba_grow(s->poI, s->pocapI, (size_t)2 * n_problems + 4))) return rc;
+    double *d_pose = s->poD, *d_xw = d_pose + (((size_t)n_problems * 7 + 1) & ~(size_t)1), *d_obs = d_xw + (size_t)n * 3,
            *d_info = d_obs + (size_t)n * 2;
-    uint8_t *d_fl = s->dB, *d_out = s->dB + n + 8;
-    int32_t *d_offs = s->dI, *d_ninl = s->dI + n_problems + 1;
+    uint8_t *d_fl = s->poB, *d_out = s->poB + n + 8;
+    int32_t *d_offs = s->poI, *d_ninl = s->poI + n_problems + 1;
     /* inputs: packed in the pinned staging buffers in the device layout and sent as ONE copy per buffer (five copies
        from pageable memory each cost a blocking bounce; Tracking calls this up to three times per frame) */
     const size_t npose = ((size_t)n_problems * 7 + 1) & ~(size_t)1, nD_in = npose + (size_t)n * 6;
-    if ((rc = ba_grow_pinned(s->pD, s->pcapD, nD_in))) return rc;
-    if ((rc = ba_grow_pinned(s->pI, s->pcapI, (size_t)2 * n_problems + 4))) return rc;
-    if ((rc = ba_grow_pinned(s->pB, s->pcapB, std::max<size_t>((size_t)n, 1)))) return rc;
-    memcpy(s->pD, poses, (size_t)n_problems * 56);
+    if ((rc = ba_grow_pinned(s->ppD, s->ppcapD, nD_in))) return rc;
+    if ((rc = ba_grow_pinned(s->ppI, s->ppcapI, (size_t)2 * n_problems + 4))) return rc;
+    if ((rc = ba_grow_pinned(s->ppB, s->ppcapB, std::max<size_t>((size_t)n, 1)))) return rc;
+    memcpy(s->ppD, poses, (size_t)n_problems * 56);
     if (n > 0) {
-        memcpy(s->pD + npose, xw, (size_t)n * 24);
-        memcpy(s->pD + npose + (size_t)n * 3, obs, (size_t)n * 16);
-        memcpy(s->pD + npose + (size_t)n * 5, inv_sigma2, (size_t)n * 8);
+        memcpy(s->ppD + npose, xw, (size_t)n * 24);
+        memcpy(s->ppD + npose + (size_t)n * 3, obs, (size_t)n * 16);
+        memcpy(s->ppD + npose + (size_t)n * 5, inv_sigma2, (size_t)n * 8);
     }
-    memcpy(s->pI, offsets, (size_t)(n_problems + 1) * 4);
-    BCHK(hipMemcpyAsync(d_pose, s->pD, nD_in * 8, hipMemcpyHostToDevice, s->stream));
-    BCHK(hipMemcpyAsync(d_offs, s->pI, (size_t)(n_problems + 1) * 4, hipMemcpyHostToDevice, s->stream));
+    memcpy(s->ppI, offsets, (size_t)(n_problems + 1) * 4);
+    BCHK(hipMemcpyAsync(d_pose, s->ppD, nD_in * 8, hipMemcpyHostToDevice, s->stream));
+    BCHK(hipMemcpyAsync(d_offs, s->ppI, (size_t)(n_problems + 1) * 4, hipMemcpyHostToDevice, s->stream));
     int maxe = 0;
     for (int p = 0; p < n_problems; p++) maxe = std::max(maxe, offsets[p + 1] - offsets[p]);
     int lds_edges = 0;
@@ -1951,20 +2313,19 @@ extern "C" int ba_pose_optimization_batch(BASolver *s, double *poses, const doub
     if (maxe > 0 && po_lds <= 96 * 1024) { /* beside the 58 KB of static LDS of the kernel */
         lds_edges = maxe;
         static PerDeviceLdsLimit po_lim;
-        if (po_lim.raise(po_lds))
-            BCHK(hipFuncSetAttribute((const void *)k_pose_opt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)po_lds));
+        BCHK(po_lim.ensure((const void *)k_pose_opt, po_lds));
     }
     hipLaunchKernelGGL(k_pose_opt, dim3(n_problems), dim3(PO_T), lds_edges ? po_lds : 0, s->stream, d_pose, (const double *)d_xw,
                        (const double *)d_obs, (const double *)d_info, d_fl, d_out, (const int32_t *)d_offs, fx, fy, cx, cy,
                        d_ninl, lds_edges);
     BCHK(hipGetLastError());
-    BCHK(hipMemcpyAsync(s->pD, d_pose, (size_t)n_problems * 56, hipMemcpyDeviceToHost, s->stream));
-    if (n > 0) BCHK(hipMemcpyAsync(s->pB, d_out, (size_t)n, hipMemcpyDeviceToHost, s->stream));
-    BCHK(hipMemcpyAsync(s->pI + n_problems + 1, d_ninl, (size_t)n_problems * 4, hipMemcpyDeviceToHost, s->stream));
+    BCHK(hipMemcpyAsync(s->ppD, d_pose, (size_t)n_problems * 56, hipMemcpyDeviceToHost, s->stream));
+    if (n > 0) BCHK(hipMemcpyAsync(s->ppB, d_out, (size_t)n, hipMemcpyDeviceToHost, s->stream));
+    BCHK(hipMemcpyAsync(s->ppI + n_problems + 1, d_ninl, (size_t)n_problems * 4, hipMemcpyDeviceToHost, s->stream));
     BCHK(hipStreamSynchronize(s->stream));
-    memcpy(poses, s->pD, (size_t)n_problems * 56);
-    if (n > 0) memcpy(outlier, s->pB, (size_t)n);
-    memcpy(n_inliers, s->pI + n_problems + 1, (size_t)n_problems * 4);
+    memcpy(poses, s->ppD, (size_t)n_problems * 56);
+    if (n > 0) memcpy(outlier, s->ppB, (size_t)n);
+    memcpy(n_inliers, s->ppI + n_problems + 1, (size_t)n_problems * 4);
     return ORB_OK;
 }
 

@@ -57,6 +57,7 @@ struct OrbExtractor {
     OrbConfig cfg;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t last_launch_stream = nullptr; /* stream of the most recent orb_extract_batch_device call */
     int max_w = 0, max_h = 0, max_batch = 0;
     std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
     std::vector<int> nfeat;
@@ -306,7 +307,7 @@ static int build_geom(OrbExtractor *h, int w, int hgt) {
     return ORB_OK;
 }
 
-static long *g_generation_sink = nullptr; /* set by the caller of grow() */
+static thread_local long *g_generation_sink = nullptr; /* set by the caller of grow(); per host thread (one handle per thread) */
 template <typename T> static int grow(T *&p, size_t &cap, size_t need) {
     if (need <= cap && p) return ORB_OK;
     if (g_generation_sink) (*g_generation_sink)++;
@@ -342,7 +343,10 @@ static int set_geometry(OrbExtractor *h, int w, int hgt) {
     g_generation_sink = &h->generation;
     int rc = build_geom(h, w, hgt);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(h->stream)); /* previous launches may still read the old tables */
+    /* previous launches may still read the old tables -- on the handle's stream or on whatever stream the caller of
+       orb_extract_batch_device last passed (nothing else orders the blocking table copies below against those) */
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->last_launch_stream && h->last_launch_stream != h->stream) HIPCHK(hipStreamSynchronize(h->last_launch_stream));
     if ((rc = grow(h->d_cells, h->cap_cells, std::max<size_t>(h->h_cells.size(), 1)))) return rc;
     if ((rc = grow(h->d_tab_i, h->cap_tab_i, std::max<size_t>(h->h_tab_i.size(), 1)))) return rc;
     if ((rc = grow(h->d_tab_c, h->cap_tab_c, std::max<size_t>(h->h_tab_c.size(), 2)))) return rc;
@@ -569,6 +573,7 @@ extern "C" int orb_extract_batch_device(OrbExtractor *h, const uint8_t *d_imgs, 
     }
     if ((rc = ensure_buffers(h, n_frames))) return rc;
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    h->last_launch_stream = st;
     const OrbGeom &g = h->geom;
     const bool prof = h->profile;
     hipEvent_t *ev = h->ev[h->prof_calls % OrbExtractor::kProfRing];

@@ -3,6 +3,7 @@
 #define ORB_COMMON_H
 
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <string>
 #include <stdint.h>
 
@@ -107,18 +108,21 @@ hipError_t launch_describe(const OrbGeom &g, const OrbBuffers &b, int n_frames, 
                            uint8_t *d_desc, int cap, int32_t *d_counts, hipStream_t st);
 
 
-/* hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember the largest size requested on each
- * (a process normally owns one GPU; racing host threads at worst set the same attribute twice) */
+/* hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember the largest size granted on each.  The
+ * check and the attribute call sit under one mutex, so a second host thread can never see the size as "already
+ * raised" and launch before the first thread's hipFuncSetAttribute has taken effect. */
 struct PerDeviceLdsLimit {
     size_t set[64] = {};
-    bool raise(size_t bytes) {
+    std::mutex mu;
+    hipError_t ensure(const void *func, size_t bytes) {
         int d = 0;
-        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
-        if (bytes > set[d]) {
-            set[d] = bytes;
-            return true;
-        }
-        return false;
+        hipError_t e = hipGetDevice(&d);
+        if (e != hipSuccess) return e;
+        std::lock_guard<std::mutex> lk(mu);
+        if (d >= 0 && d < 64 && bytes <= set[d]) return hipSuccess;
+        e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e == hipSuccess && d >= 0 && d < 64) set[d] = bytes;
+        return e;
     }
 };
 

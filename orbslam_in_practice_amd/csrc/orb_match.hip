@@ -798,7 +798,7 @@ static int launch_match(const MatchArgs &A_in, int n_pairs, hipStream_t st, hipE
         return ORB_E_CAPACITY;
     }
     static PerDeviceLdsLimit lim;
-    if (lim.raise(lds)) MCHK(hipFuncSetAttribute((const void *)k_match_init, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MCHK(lim.ensure((const void *)k_match_init, lds));
     if (A.cap <= (A.window < 0 ? 65536 : 2048))
         hipLaunchKernelGGL(k_match_knn<true>, dim3((A.cap + 255) / 256, n_pairs), dim3(256), 0, st, A);
     else

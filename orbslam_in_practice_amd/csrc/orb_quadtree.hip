@@ -475,8 +475,8 @@ template <int NN> static hipError_t launch_qt(const OrbGeom &g, const OrbBuffers
     const int lds_keys = n_frames <= 8 ? (int)std::min<size_t>(12288, room / 8) : 0;
     const size_t lds = ((sizeof(QtShared<NN>) + 15) & ~(size_t)15) + (size_t)lds_keys * 8;
     static PerDeviceLdsLimit lim2;
-    if (lim2.raise(lds)) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_quadtree<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        hipError_t e = lim2.ensure((const void *)k_quadtree<NN>, lds);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_quadtree<NN>, grid, dim3(NN / 2), lds, st, g, b.cells, (const uint32_t *)b.slab,

@@ -56,7 +56,7 @@ class Optimizer:
         P.stop = stop.ctypes.data if stop is not None else None
         return keep
 
-    def solve_batch(self, windows, rounds, robust=True, chi2_threshold=CHI2_2D, drop_robust_after=0, stop=None):
+    def _prepare(self, windows, rounds, robust, chi2_threshold, drop_robust_after, stop):
         n = len(windows)
         Ps = (BAProblem * n)()
         Rs = (BAResult * n)()
@@ -72,13 +72,42 @@ class Optimizer:
         for i in range(n):
             Rs[i].poses, Rs[i].points, Rs[i].outlier = bp + int(oc[i]) * 56, bx + int(op[i]) * 24, bo + int(oe[i])
             outs.append(dict(poses=Pb[oc[i]:oc[i + 1]], points=Xb[op[i]:op[i + 1]], outlier=Ob[oe[i]:oe[i + 1]]))
-        check(self._L.ba_solve_batch(self._s, Ps, Rs, n))
-        for i, o in enumerate(outs):
+        return dict(n=n, Ps=Ps, Rs=Rs, keep=keep, outs=outs, bufs=(Pb, Xb, Ob))
+
+    @staticmethod
+    def _collect(job):
+        Ps, Rs = job["Ps"], job["Rs"]
+        for i, o in enumerate(job["outs"]):
             o["outlier"] = o["outlier"][:Ps[i].n_obs]
             o.update(chi2_initial=Rs[i].chi2_initial, chi2_final=Rs[i].chi2_final, iterations=Rs[i].iterations,
                      lin_solves=Rs[i].lin_solves)
-        del keep
-        return outs
+        return job["outs"]
+
+    def solve_batch(self, windows, rounds, robust=True, chi2_threshold=CHI2_2D, drop_robust_after=0, stop=None):
+        job = self._prepare(windows, rounds, robust, chi2_threshold, drop_robust_after, stop)
+        check(self._L.ba_solve_batch(self._s, job["Ps"], job["Rs"], job["n"]))
+        return self._collect(job)
+
+    def submit_batch(self, windows, rounds, robust=True, chi2_threshold=CHI2_2D, drop_robust_after=0):
+        """ba_submit_batch: stage + enqueue, returns at once (two batches may be in flight); pair with wait()"""
+        job = self._prepare(windows, rounds, robust, chi2_threshold, drop_robust_after, None)
+        check(self._L.ba_submit_batch(self._s, job["Ps"], job["Rs"], job["n"]))
+        self._jobs = getattr(self, "_jobs", [])
+        self._jobs.append(job)   # keeps every buffer the C side points into alive until wait()
+
+    def wait(self):
+        """ba_wait: results of the OLDEST submitted batch"""
+        check(self._L.ba_wait(self._s))
+        return self._collect(self._jobs.pop(0))
+
+    def set_profiling(self, on=True):
+        check(self._L.ba_set_profiling(self._s, 1 if on else 0))
+
+    def iteration_ms(self):
+        """(average k_ba_iteration launch in ms, launches, workgroups per window) of the last finished batch"""
+        ms, nl, team = C.c_float(0), C.c_int32(0), C.c_int32(0)
+        check(self._L.ba_get_iteration_ms(self._s, C.byref(ms), C.byref(nl), C.byref(team)))
+        return ms.value, nl.value, team.value
 
     # ---- the reference's entry points (include/Optimizer.h:11-19) ----
     def BundleAdjustment(self, window, nIterations=5, pbStopFlag=None, nLoopKF=0, bRobust=True):

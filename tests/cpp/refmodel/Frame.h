@@ -1,0 +1,2 @@
+/* test stand-in, see refmodel.h */
+#include "refmodel.h"

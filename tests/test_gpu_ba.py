@@ -46,17 +46,94 @@ def test_ba_matches_oracle(opt, oracle, nc, npt, rounds, nfix):
         assert got["chi2_final"] < 0.2 * got["chi2_initial"]
 
 
-def test_ba_global_gauge_free_cost(opt, oracle):
-    """Optimizer::BundleAdjustment exactly as the reference builds it (20 robust iterations, only KF 0
-    fixed, outliers never removed).  The monocular scale gauge is free, lambda falls to ~1e-10 of the
-    Hessian diagonal and the damped system's condition number reaches ~1e10, so late iterations of ANY two
-    linear solvers part ways along the gauge orbit; what is comparable is the (gauge-invariant) cost."""
+def _check_estimates(got, ref, tol=REL):
+    assert got["iterations"] == ref["iterations"]
+    assert np.array_equal(got["outlier"], ref["outlier"])
+    assert _rel(got["points"], ref["points"]) < tol
+    assert _rel(got["poses"][:, 4:], ref["poses"][:, 4:]) < tol
+    assert np.abs(got["poses"][:, :4] - ref["poses"][:, :4]).max() < tol
+    assert abs(got["chi2_final"] - ref["chi2_final"]) <= tol * ref["chi2_final"]
+
+
+@pytest.mark.parametrize("nc,npt,outl,its", [(2, 300, 0.05, 20),      # src/Tracking.cpp:254: the initial two-keyframe map
+                                             (3, 500, 0.05, 10),
+                                             (50, 2000, 0.0, 20),     # BASELINE configs[2] size, inlier noise only
+                                             (50, 2000, 0.05, 12),    # ... with 5 % gross outliers: the well-posed prefix
+                                             (100, 5000, 0.0, 20)])
+def test_ba_global_reference_graph(opt, oracle, nc, npt, outl, its):
+    """a13 exactly as the reference builds it (src/Optimizer.cpp:43-58, :100-105, :124): ONLY keyframe 0 fixed (the
+    monocular scale gauge stays free), robust kernel on every edge, one optimize(nIterations), outliers never
+    removed.  Pose and point estimates within 1e-5 relative of the oracle, f64 on both sides."""
+    from orbslam_in_practice_amd import synth
+    w = synth.make_ba_window(99 + nc, nc, npt, outlier_frac=outl)
+    assert w["fixed"].sum() == 1 and w["fixed"][0] == 1
+    ref = oracle.ba_solve(w, rounds=(its,))
+    got = opt.solve_batch([w], (its,))[0]
+    _check_estimates(got, ref)
+
+
+def _residuals(r, w):
+    q = r["poses"][:, :4]
+    qw, qx, qy, qz = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = np.stack([1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw),
+                  2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw),
+                  2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)], axis=1).reshape(-1, 3, 3)
+    pc = np.einsum("eij,ej->ei", R[w["cam_idx"]], r["points"][w["pt_idx"]]) + r["poses"][w["cam_idx"], 4:]
+    return np.stack([w["obs"][:, 0] - (w["fx"] * pc[:, 0] / pc[:, 2] + w["cx"]),
+                     w["obs"][:, 1] - (w["fy"] * pc[:, 1] / pc[:, 2] + w["cy"])], axis=1)
+
+
+def test_ba_global_reference_graph_outliers_20_iterations(opt, oracle):
+    """The same graph at 50 x 2000 with 5 % gross outliers and the full 20 iterations.  Here the PROBLEM is unstable,
+    not a solver: the oracle run twice, the second time with its input points scaled by (1 + 1e-13), agrees with itself
+    to 1e-11 through iteration 12 and then parts ways by three orders of magnitude every few iterations (lambda has
+    fallen to ~1e-10 of the Hessian diagonal, the Huber-weighted outliers are never switched off and the cost keeps
+    creeping down a flat valley) -- 3e-3 in the points at iteration 20.  No two f64 implementations can agree to 1e-5
+    there (g2o built with another compiler would not either), so the test (a) holds the device to 1e-5 on the
+    well-conditioned prefix (parametrised case above), (b) measures the problem's own sensitivity with the oracle and
+    requires the device to stay within it, and (c) compares what IS stable: the gauge-invariant cost to 1e-5."""
     from orbslam_in_practice_amd import synth
     w = synth.make_ba_window(50 * 7 + 2000, 50, 2000)
     ref = oracle.ba_solve(w, rounds=(20,))
+    wp = dict(w)
+    wp["points"] = w["points"] * (1 + 1e-13)
+    alt = oracle.ba_solve(wp, rounds=(20,))
     got = opt.solve_batch([w], (20,))[0]
     assert got["iterations"] == ref["iterations"] == 20
-    assert abs(got["chi2_final"] - ref["chi2_final"]) < 1e-3 * ref["chi2_final"]
+    assert abs(got["chi2_final"] - ref["chi2_final"]) < REL * ref["chi2_final"]
+    own = max(_rel(alt["points"], ref["points"]), REL)
+    assert _rel(got["points"], ref["points"]) < 20 * own
+    r_ref, r_alt, r_got = _residuals(ref, w), _residuals(alt, w), _residuals(got, w)
+    inl = np.abs(r_ref).max(axis=1) < 20.0
+    own_r = max(np.abs(r_alt - r_ref)[inl].max(), REL * np.abs(r_ref[inl]).max())
+    assert np.abs(r_got - r_ref)[inl].max() < 20 * own_r
+
+
+def test_ba_degenerate_windows(opt, oracle):
+    """all cameras fixed (no reduced system: structure-only refinement), no observations at all, and a
+    window whose points each have a single observation (Hll singular until lambda is added)"""
+    from orbslam_in_practice_amd import synth
+    w = synth.make_ba_window(8, 6, 200)
+    wf = dict(w)
+    wf["fixed"] = np.ones(6, np.uint8)
+    ref = oracle.ba_solve(wf, rounds=(5, 10))
+    got = opt.solve_batch([wf], (5, 10))[0]
+    _check_estimates(got, ref)
+    assert np.array_equal(got["poses"], w["poses"] * np.sign(w["poses"][:, :1]))
+    assert got["chi2_final"] < got["chi2_initial"]
+    we = dict(w)
+    for k in ("obs", "cam_idx", "pt_idx", "inv_sigma2"):
+        we[k] = w[k][:0]
+    got = opt.solve_batch([we], (5, 10))[0]
+    assert got["chi2_final"] == 0.0 and np.array_equal(got["points"], w["points"])
+    first = np.unique(w["pt_idx"], return_index=True)[1]
+    w1 = dict(w)
+    for k in ("obs", "cam_idx", "pt_idx", "inv_sigma2"):
+        w1[k] = w[k][first]
+    ref = oracle.ba_solve(w1, rounds=(5,))
+    got = opt.solve_batch([w1], (5,))[0]
+    assert np.isfinite(got["points"]).all() and np.isfinite(got["poses"]).all()
+    assert abs(got["chi2_final"] - ref["chi2_final"]) <= 1e-6 * max(ref["chi2_final"], 1.0)
 
 
 def test_ba_batch_equals_single(opt, oracle):
@@ -65,7 +142,9 @@ def test_ba_batch_equals_single(opt, oracle):
     batch = opt.solve_batch(ws, (5, 10))
     for w, b in zip(ws, batch):
         single = opt.solve_batch([w], (5, 10))[0]
-        assert np.array_equal(single["points"], b["points"])  # bit-reproducible: no atomics
+        # no atomics anywhere: bit-reproducible for a given team size; the team size (workgroups per window) follows
+        # the batch's largest window, so a window solved alone may sum in another order -- rounding level only
+        assert _rel(single["points"], b["points"]) < 1e-9
         ref = oracle.ba_solve(w, rounds=(5, 10))
         assert _rel(b["points"], ref["points"]) < REL
 
@@ -202,4 +281,81 @@ def test_ba_many_cameras_envelope_panel(oracle):
     assert np.array_equal(got["outlier"], ref["outlier"])
     assert _rel(got["points"], ref["points"]) < REL
     assert _rel(got["poses"][:, 4:], ref["poses"][:, 4:]) < REL
+    o.close()
+
+
+@pytest.mark.parametrize("nc,npt", [(12, 400), (100, 5000)])
+def test_ba_team_sizes_agree(oracle, nc, npt, monkeypatch):
+    """one window spread over 1, 4 and 64 cooperating workgroups (device-side phase barriers): same estimates to
+    rounding, each within 1e-5 of the oracle, and the profiling hook reports the team that ran"""
+    import orbslam_in_practice_amd as oa
+    from orbslam_in_practice_amd import synth
+    w = synth.make_ba_window(2024 + nc, nc, npt)
+    w["fixed"][:2] = 1
+    ref = oracle.ba_solve(w, rounds=(5, 10))
+    outs = {}
+    for g in (1, 4, 64):
+        monkeypatch.setenv("ORBSLAM_AMD_BA_TEAM", str(g))
+        o = oa.Optimizer(max_cams=nc, max_points=npt, max_obs=8 * npt, max_batch=1)
+        o.set_profiling(True)
+        outs[g] = o.solve_batch([w], (5, 10))[0]
+        ms, launches, team = o.iteration_ms()
+        assert team == g and launches == 15 and ms > 0
+        o.close()
+        _check_estimates(outs[g], ref)
+    for g in (4, 64):
+        assert np.array_equal(outs[g]["outlier"], outs[1]["outlier"])
+        assert _rel(outs[g]["points"], outs[1]["points"]) < 1e-8
+        assert _rel(outs[g]["poses"], outs[1]["poses"]) < 1e-8
+
+
+def test_ba_submit_wait_pipeline(opt, oracle):
+    """ba_submit_batch / ba_wait: two batches in flight, results in submission order and equal to the synchronous
+    call; a third submit without a wait is refused"""
+    import orbslam_in_practice_amd as oa
+    from orbslam_in_practice_amd import synth
+    batches = [[synth.make_ba_window(5000 + 10 * b + i, 10 + i, 250 + 30 * i) for i in range(4)] for b in range(3)]
+    sync = [opt.solve_batch(ws, (5, 10)) for ws in batches]
+    opt.submit_batch(batches[0], (5, 10))
+    opt.submit_batch(batches[1], (5, 10))
+    with pytest.raises(oa.OrbError) as ei:
+        opt.submit_batch(batches[2], (5, 10))
+    assert ei.value.code == oa._lib.ORB_E_BUSY
+    opt._jobs.pop()                      # the refused job never reached the device
+    got0 = opt.wait()
+    opt.submit_batch(batches[2], (5, 10))
+    got1 = opt.wait()
+    got2 = opt.wait()
+    for got, ref in zip((got0, got1, got2), sync):
+        for a, b in zip(got, ref):
+            assert np.array_equal(a["points"], b["points"]) and np.array_equal(a["poses"], b["poses"])
+            assert np.array_equal(a["outlier"], b["outlier"]) and a["chi2_final"] == b["chi2_final"]
+    r = oracle.ba_solve(batches[2][3], rounds=(5, 10))
+    assert _rel(got2[3]["points"], r["points"]) < REL
+
+
+def test_ba_more_than_256_free_cameras(oracle):
+    """g2o has no camera limit.  270 free cameras (reduced system 1620 > the 1536 rows of the LDS vectors): a
+    chain-like window still fits the envelope Cholesky; the same window with its cameras shuffled has a nearly dense
+    envelope, no LDS panel fits, and the in-kernel PCG runs with its vectors in HBM.  Both agree with the oracle."""
+    import orbslam_in_practice_amd as oa
+    from orbslam_in_practice_amd import synth
+    w = synth.make_ba_window(4243, 272, 3500)
+    w["fixed"][:2] = 1
+    ref = oracle.ba_solve(w, rounds=(3, 2))
+    o = oa.Optimizer(max_cams=272, max_points=3500, max_obs=32768, max_batch=1)
+    got = o.solve_batch([w], (3, 2))[0]
+    _check_estimates(got, ref)
+    rng = np.random.default_rng(9)
+    perm = np.concatenate([[0, 1], 2 + rng.permutation(270)])
+    inv = np.empty(272, np.int64)
+    inv[perm] = np.arange(272)
+    ws = dict(w)
+    ws["poses"], ws["fixed"] = w["poses"][perm].copy(), w["fixed"][perm].copy()
+    ws["cam_idx"] = inv[w["cam_idx"]].astype(np.int32)
+    got2 = o.solve_batch([ws], (3, 2))[0]
+    assert got2["iterations"] == ref["iterations"]
+    assert np.array_equal(got2["outlier"], ref["outlier"])
+    assert _rel(got2["points"], ref["points"]) < REL
+    assert _rel(got2["poses"][inv][:, 4:], ref["poses"][:, 4:]) < REL
     o.close()

@@ -151,3 +151,66 @@ def test_measurement_hooks_report_every_stage():
     assert 0.0 < tot.value < 50.0
     m.close()
     ext.close()
+
+
+def test_config3_per_rank_share_64x1280x720(oracle):
+    """BASELINE configs[3] at its per-GPU size: 512 frames of 1280x720 over 8 GPUs = 64 per rank, through
+    orb_extract_batch_device + orb_match_batch_device (what a rank of bench.py runs), oracle parity on frames
+    spread over the batch, and on the pairs they form with their successors; batch-position independence and
+    determinism for every frame."""
+    import hashlib
+    import orbslam_in_practice_amd as oa
+    from orbslam_in_practice_amd import shard, synth
+    B, W, H, nf = 64, 1280, 720, 1000
+    frames = synth.make_stream(333, B, W, H)
+    dev = torch.device("cuda", 0)
+    ext = oa.ORBextractor(nf, 1.2, 8, 20, 7, max_w=W, max_h=H, max_batch=B)
+    cap = ext.cap
+    m = oa.ORBmatcher(0.9, True, max_keypoints=cap, max_pairs=B)
+    d_img = torch.from_numpy(frames).to(dev)
+    pa_h, pb_h = shard.stream_pairs(0, 1, B)
+    pa, pb = torch.from_numpy(pa_h).to(dev), torch.from_numpy(pb_h).to(dev)
+    st = torch.cuda.Stream(device=dev)
+    sp = C.c_void_p(st.cuda_stream)
+    bounds = (0.0, float(W), 0.0, float(H))
+    runs = []
+    for rep in range(2):
+        d_kps = torch.full((B, cap, 28), 0xAB if rep else 0, dtype=torch.uint8, device=dev)
+        d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+        d_cnt = torch.zeros((B,), dtype=torch.int32, device=dev)
+        d_m12 = torch.full((B, cap), -7, dtype=torch.int32, device=dev)
+        d_nm = torch.zeros((B,), dtype=torch.int32, device=dev)
+        with torch.cuda.stream(st):
+            ext.extract_batch_device(d_img.data_ptr(), B, W, H, W, W * H, d_kps.data_ptr(), d_desc.data_ptr(), cap,
+                                     d_cnt.data_ptr(), sp)
+            m.match_batch_device(d_kps.data_ptr(), d_desc.data_ptr(), d_cnt.data_ptr(), cap, pa.data_ptr(), pb.data_ptr(),
+                                 B, bounds, -1, d_m12.data_ptr(), d_nm.data_ptr(), sp)
+        torch.cuda.synchronize()
+        runs.append((d_cnt.cpu().numpy(), _np_kps(d_kps, oracle), d_desc.cpu().numpy(), d_m12.cpu().numpy(), d_nm.cpu().numpy()))
+    cnt, kps, desc, m12, nm = runs[0]
+    cnt2, kps2, desc2, m122, nm2 = runs[1]
+    assert np.array_equal(cnt, cnt2) and np.array_equal(nm, nm2)
+    for i in range(B):   # deterministic, and independent of what the output slabs held before
+        assert np.array_equal(kps[i, :cnt[i]], kps2[i, :cnt[i]]) and np.array_equal(desc[i, :cnt[i]], desc2[i, :cnt[i]])
+        assert np.array_equal(m12[i, :cnt[pa_h[i]]], m122[i, :cnt[pa_h[i]]])
+        assert cnt[i] >= nf
+    o = oracle.OrbOracle(nf, 1.2, 8, 20, 7)
+    feats = {}
+    for i in (0, 1, 21, 22, 42, 43, 62, 63):
+        feats[i] = o.extract(frames[i])
+        assert cnt[i] == len(feats[i][0])
+        assert np.array_equal(kps[i, :cnt[i]], feats[i][0]) and np.array_equal(desc[i, :cnt[i]], feats[i][1]), i
+    for p in (0, 21, 42, 62):
+        a, b = int(pa_h[p]), int(pb_h[p])
+        assert (a, b) == (p, p + 1)
+        on, om12, _ = oracle.search_for_initialization(feats[a][0], feats[a][1], feats[b][0], feats[b][1], bounds, None,
+                                                       -1, 0.9, True)
+        assert nm[p] == on and on > 50 and np.array_equal(m12[p, :cnt[a]], om12), (p, nm[p], on)
+    # the single-frame host path gives the same answer for frames the oracle did not see
+    e1 = oa.ORBextractor(nf, 1.2, 8, 20, 7, max_w=W, max_h=H, max_batch=1)
+    for i in (7, 33, 57):
+        k1, d1 = e1(frames[i])
+        assert np.array_equal(k1, kps[i, :cnt[i]]) and np.array_equal(d1, desc[i, :cnt[i]])
+    e1.close()
+    m.close()
+    ext.close()

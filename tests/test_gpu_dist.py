@@ -1,0 +1,97 @@
+"""GPU rehearsal of the multi-rank hand-off on ONE card: two ranks (processes) share cuda:0, gloo stands in for RCCL
+(there is a single GPU here; the 8-GPU run is the driver's).  Every rank extracts its own block on the DEVICE, the
+halo exchange (orbslam_in_practice_amd/shard.py, exactly what bench.py calls) brings in the neighbour's first frame
+slab, the DEVICE matcher runs on local row indices -- and the matches must equal a single-rank device run over the
+whole stream and the oracle."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H, B, NF = 640, 480, 3, 1000
+
+
+def _device_run(frames, rank, world, exchange):
+    import orbslam_in_practice_amd as oa
+    from orbslam_in_practice_amd import shard
+    dev = torch.device("cuda", 0)
+    ext = oa.ORBextractor(NF, 1.2, 8, 20, 7, max_w=W, max_h=H, max_batch=B)
+    cap = ext.cap
+    m = oa.ORBmatcher(0.9, True, max_keypoints=cap, max_pairs=B)
+    rows = shard.halo_rows(world, B)
+    d_img = torch.from_numpy(frames).to(dev)
+    d_kps = torch.zeros((rows, cap, 28), dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros((rows, cap, 32), dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros((rows,), dtype=torch.int32, device=dev)
+    d_m12 = torch.full((B, cap), -7, dtype=torch.int32, device=dev)
+    d_nm = torch.zeros((B,), dtype=torch.int32, device=dev)
+    pa_h, pb_h = shard.halo_pairs(rank, world, B)
+    pa, pb = torch.from_numpy(pa_h).to(dev), torch.from_numpy(pb_h).to(dev)
+    st = torch.cuda.Stream(device=dev)
+    sp = C.c_void_p(st.cuda_stream)
+    with torch.cuda.stream(st):
+        ext.extract_batch_device(d_img.data_ptr(), B, W, H, W, W * H, d_kps.data_ptr(), d_desc.data_ptr(), cap,
+                                 d_cnt.data_ptr(), sp)
+        if exchange is not None:
+            exchange(d_kps, d_desc, d_cnt)
+        m.match_batch_device(d_kps.data_ptr(), d_desc.data_ptr(), d_cnt.data_ptr(), cap, pa.data_ptr(), pb.data_ptr(), B,
+                             (0.0, float(W), 0.0, float(H)), -1, d_m12.data_ptr(), d_nm.data_ptr(), sp)
+    torch.cuda.synchronize()
+    cnt = d_cnt.cpu().numpy()
+    out = [(int(n), d_m12[i, :cnt[i]].cpu().numpy().tolist()) for i, n in enumerate(d_nm.cpu().numpy())]
+    m.close()
+    ext.close()
+    return out, cnt.tolist()
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from orbslam_in_practice_amd import shard, synth
+    frames = synth.make_stream(77, world * B, W, H)
+    lo, hi = shard.owned_range(world * B, rank, world)
+    out, cnt = _device_run(frames[lo:hi], rank, world, shard.HaloExchange(world, B))
+    q.put((rank, out, cnt))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_device_slabs_through_halo_exchange(oracle):
+    import torch.multiprocessing as mp
+    from orbslam_in_practice_amd import synth
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        rank, out, cnt = q.get(timeout=600)
+        got[rank] = (out, cnt)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    frames = synth.make_stream(77, world * B, W, H)
+    o = oracle.OrbOracle(NF, 1.2, 8, 20, 7)
+    feats = [o.extract(f) for f in frames]
+    bounds = (0.0, float(W), 0.0, float(H))
+    for r in range(world):
+        out, cnt = got[r]
+        assert cnt[:B] == [len(feats[r * B + i][0]) for i in range(B)]
+        assert cnt[B:] == [len(feats[q_ * B][0]) for q_ in range(world)]      # halo rows: every rank's first frame
+        for i in range(B):
+            a, b = r * B + i, (r * B + i + 1) % (world * B)
+            on, om12, _ = oracle.search_for_initialization(feats[a][0], feats[a][1], feats[b][0], feats[b][1], bounds, None,
+                                                           -1, 0.9, True)
+            assert out[i][0] == on and out[i][1] == om12.tolist(), (r, i)
+    assert got[0][0][B - 1][0] > 50      # the cross-rank pair (rank 0's last frame -> rank 1's first) has real matches
