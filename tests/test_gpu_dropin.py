@@ -115,7 +115,9 @@ def test_cpp_dropin_every_method(oracle, tmp_path):
     golden["frame0"].tofile(os.path.join(td, "f0.raw"))
     golden["frame1"].tofile(os.path.join(td, "f1.raw"))
     NC, NPT = 30, 1200
-    w = synth.make_ba_window(31337, NC, NPT)
+    # inlier noise only: with gross outliers kept on Huber edges for 20 gauge-free iterations the window itself is
+    # unstable (tools/ba_sensitivity.py) and not even two runs of one implementation would agree
+    w = synth.make_ba_window(31337, NC, NPT, outlier_frac=0.0)
     w2, octv = _as_cpp_sees_it(w)
     with open(os.path.join(td, "win.bin"), "wb") as f:
         np.array([NC, NPT, len(w["obs"])], np.int32).tofile(f)
@@ -167,7 +169,7 @@ def test_cpp_dropin_every_method(oracle, tmp_path):
     r_abi = _reproj_residuals(Rg, got["poses"][:, 4:], got["points"], w2)
     Rr = np.array([_quat_to_R(q) for q in ref["poses"][:, :4]])
     r_orc = _reproj_residuals(Rr, ref["poses"][:, 4:], ref["points"], w2)
-    inl = np.abs(r_orc).max(axis=1) < 20          # outliers (5 %) have residuals of hundreds of px
+    inl = np.abs(r_orc).max(axis=1) < 20
     scale = np.abs(r_orc[inl]).max()
     assert np.abs(r_cpp - r_abi)[inl].max() < 1e-7 * scale
     assert np.abs(r_cpp - r_orc)[inl].max() < REL * scale
@@ -218,7 +220,8 @@ def test_cpp_dropin_every_method(oracle, tmp_path):
     rp, ro, rn = oracle.pose_optimization(w2["poses"][cur], xw, w2["obs"][sel[has]], w2["inv_sigma2"][sel[has]],
                                           w2["fx"], w2["fy"], w2["cx"], w2["cy"])
     assert ret == gn == rn and 3 < ret < has.sum()
-    assert np.array_equal(outl[has], go) and np.array_equal(go, ro) and not outl[~has].any()
+    assert np.array_equal(outl[has], go) and np.array_equal(go, ro)
+    assert outl[~has].all()      # slots without a map point are not touched (src/Optimizer.cpp:172-176): the test set them
     assert np.abs(T[:3, :3] - _quat_to_R(gp[:4])).max() < 1e-9 and np.abs(T[:3, 3] - gp[4:]).max() < 1e-9
     assert np.abs(T[:3, 3] - rp[4:]).max() < REL * np.abs(rp[4:]).max()
     assert np.array_equal(T[3], [0, 0, 0, 1])
