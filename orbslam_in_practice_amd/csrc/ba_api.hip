@@ -74,6 +74,7 @@ struct BAWin {
 };
 /* LM state (doubles at D[st + i]) */
 enum { ST_LAMBDA = 0, ST_NI, ST_CHI, ST_CHI0, ST_ITERS, ST_SOLVES, ST_TERM, ST_ROUND_IT, ST_HAVE_CHI0, ST_PCG_ITERS,
+       ST_ABORT, /* a team barrier gave up waiting (never expected; the host turns it into an error) */
        ST_T0, /* 10 phase timers (profile mode), 100 MHz ticks */
        ST_COUNT = ST_T0 + 10 };
 
@@ -265,13 +266,20 @@ __device__ __forceinline__ double block_max(double v, BAShared &s) {
  * order: deterministic, and for G == 1 bit-identical to the single-workgroup code. */
 struct BATeam {
     int G, part;
-    unsigned *bar;  /* this launch's arrival counter */
-    unsigned epoch; /* barriers passed so far in this launch (uniform) */
-    double *red;    /* [2 slots][2 values][BA_GMAX] */
+    unsigned *bar;   /* this launch's arrival counter */
+    unsigned *abort; /* sticky: some barrier of this window timed out */
+    unsigned epoch;  /* barriers passed so far in this launch (uniform) */
+    double *red;     /* [2 slots][2 values][BA_GMAX] */
     int slot;
+    bool dead;       /* uniform: this workgroup has seen the abort word -- barriers degrade to __syncthreads() */
 };
-__device__ __forceinline__ void team_sync(BATeam &t) {
-    if (t.G == 1) {
+#define BA_SPIN_LIMIT (1u << 23) /* x ~0.1 us: about a second -- a healthy barrier completes in microseconds */
+/* EXIT CONDITION: the spin is bounded.  If a team member never arrives (it cannot with a cooperative launch, but a
+ * kernel must drain whatever happens), the waiting lane raises the window's abort word; every workgroup of the
+ * team that sees it stops waiting at this and all later barriers, runs its (bounded) loops to the end on whatever
+ * data it has and exits; the host reports ORB_E_HIP for the batch. */
+__device__ __forceinline__ void team_sync(BATeam &t, BAShared &s) {
+    if (t.G == 1 || t.dead) {
         __syncthreads();
         return;
     }
@@ -281,9 +289,21 @@ __device__ __forceinline__ void team_sync(BATeam &t) {
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(t.bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = t.epoch * (unsigned)t.G;
-        while (__hip_atomic_load(t.bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+        unsigned spins = 0;
+        bool dead = false;
+        while (__hip_atomic_load(t.bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if ((++spins & 1023u) == 0 &&
+                (spins >= BA_SPIN_LIMIT || __hip_atomic_load(t.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                __hip_atomic_store(t.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dead = true;
+                break;
+            }
+        }
+        s.bc[7] = dead ? 1.0 : 0.0;
     }
     __syncthreads();
+    t.dead = s.bc[7] != 0.0;
     __threadfence(); /* acquire: later loads of every wave see the other parts' stores */
 }
 /* sums of a and b over all threads of the team (b may be unused) */
@@ -297,7 +317,7 @@ __device__ __forceinline__ void team_sum2(double &a, double &b, BAShared &s, BAT
         r[t.part] = a;
         r[BA_GMAX + t.part] = b;
     }
-    team_sync(t);
+    team_sync(t, s);
     double ta = 0, tb = 0;
     for (int g = 0; g < t.G; g++) {
         ta += __hip_atomic_load(r + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -313,7 +333,7 @@ __device__ __forceinline__ double team_sum(double v, BAShared &s, BATeam &t) {
     double *r = t.red + t.slot * 2 * BA_GMAX;
     t.slot ^= 1;
     if (threadIdx.x == 0) r[t.part] = v;
-    team_sync(t);
+    team_sync(t, s);
     for (int g = 0; g < t.G; g++) z += __hip_atomic_load(r + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return z;
 }
@@ -323,7 +343,7 @@ __device__ __forceinline__ double team_max(double v, BAShared &s, BATeam &t) {
     double *r = t.red + t.slot * 2 * BA_GMAX;
     t.slot ^= 1;
     if (threadIdx.x == 0) r[t.part] = v;
-    team_sync(t);
+    team_sync(t, s);
     double z = __hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int g = 1; g < t.G; g++) z = fmax(z, __hip_atomic_load(r + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     return z;
@@ -642,9 +662,13 @@ __device__ __noinline__ bool ba_pcg_global(const BAWin &w, double *D, const int3
     return ok;
 }
 
-/* one LM iteration (OptimizationAlgorithmLevenberg::solve) for every window of the batch */
+/* n_iters LM iterations (OptimizationAlgorithmLevenberg::solve) for every window of the batch.  A whole optimize()
+ * round runs in ONE launch unless a stop flag has to be polled by the host between iterations: the windows of a batch
+ * then advance independently (a window that needs a second LM trial in some iteration does not hold up the other 255,
+ * which a launch per iteration did -- the launch lasted as long as its slowest window). */
 __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of_round, double pcg_tol2, int pcg_maxit,
-                                                       int debug, int solver, int dyn_doubles, int G, int launch_seq) {
+                                                       int debug, int solver, int dyn_doubles, int G, int launch_seq,
+                                                       int n_iters) {
     __shared__ BAShared s;
     extern __shared__ __attribute__((aligned(16))) double ba_dyn[];
     /* workgroups [win * G, win * G + G) are the team of window `win` */
@@ -659,9 +683,11 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
     team.G = G;
     team.part = __builtin_amdgcn_readfirstlane((int)blockIdx.x - win * G);
     team.bar = (unsigned *)(bufs.I + w.gbar) + (launch_seq & 1);
+    team.abort = (unsigned *)(bufs.I + w.gbar) + 2;
     team.epoch = 0;
     team.red = D + w.gred;
     team.slot = 0;
+    team.dead = false;
     /* the OTHER arrival counter serves the next launch and nobody is using it now; every launch clears it, also one
        that returns on the next line, so that a launch always finds its own counter at zero */
     if (G > 1 && team.part == 0 && tid == 0)
@@ -683,6 +709,8 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
         }                                                                     \
     }
 
+    double lambda = st[ST_LAMBDA], ni = st[ST_NI]; /* uniform over the team from here on (every sum is a team sum) */
+    for (int iter = 0; iter < n_iters; iter++) {
     /* ---- computeActiveErrors + activeRobustChi2 ---- */
     double currentChi = team_sum(eval_chi2_partial(w, D, I, B, w.poses, w.pts, w.err, team), s, team);
     if (lead && tid == 0 && st[ST_HAVE_CHI0] == 0.0) {
@@ -804,12 +832,11 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
             for (int a = 0; a < 6; a++) D[w.bp + (int64_t)sl * 6 + a] = acc[21 + a];
         }
     }
-    team_sync(team);
+    team_sync(team, s);
 
     BA_STAMP(2)
     /* ---- computeLambdaInit on the first iteration of an optimize() call ---- */
-    double lambda = st[ST_LAMBDA], ni = st[ST_NI];
-    if (first_of_round) {
+    if (first_of_round && iter == 0) {
         double m = 0;
         for (int i = gtid; i < w.Ncf * 6; i += gthreads) m = fmax(m, fabs(D[w.Hpp + (int64_t)(i / 6) * 36 + (i % 6) * 7]));
         for (int i = gtid; i < w.Np * 3; i += gthreads) m = fmax(m, fabs(D[w.Hll + (int64_t)(i / 3) * 9 + (i % 3) * 4]));
@@ -844,7 +871,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
             Iv[8] = (Dm[0] * Dm[4] - Dm[1] * Dm[3]) * id;
             for (int i = 0; i < 9; i++) D[w.Dinv + (int64_t)p * 9 + i] = Iv[i];
         }
-        team_sync(team);
+        team_sync(team, s);
         /* Y = W Dinv, one thread per (edge, row of W): neighbouring threads touch neighbouring 24-B rows */
         for (int t = gtid; t < w.E * 6; t += gthreads) {
             const int e = t / 6, a = t - e * 6;
@@ -856,7 +883,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
             Yr[1] = w0 * Iv[1] + w1 * Iv[4] + w2 * Iv[7];
             Yr[2] = w0 * Iv[2] + w1 * Iv[5] + w2 * Iv[8];
         }
-        team_sync(team);
+        team_sync(team, s);
         BA_STAMP(3)
         /* ---- S = Hpp + lambda I - sum Y W^T : one wavefront per non-zero 6x6 block.  Each LANE takes whole
            contributions (stride 64: 64 independent Y/W gathers in flight), accumulates its own 6x6 partial in
@@ -913,7 +940,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
                 for (int i = 0; i < 36; i++) D[w.S + (int64_t)bk * 36 + i] = -acc[i];
             }
         }
-        team_sync(team);
+        team_sync(team, s);
         /* S is symmetric: only blocks on or above the diagonal carry contribution lists; the others are the
            transposes of their mirrors */
         for (int i = gtid; i < w.nnzb * 36; i += gthreads) {
@@ -921,7 +948,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
             const int mk = I[w.blk_mirror + bk];
             if (mk < bk) D[w.S + i] = D[w.S + (int64_t)mk * 36 + (e % 6) * 6 + e / 6];
         }
-        team_sync(team);
+        team_sync(team, s);
         BA_STAMP(4)
         /* diagonal blocks: + Hpp + lambda I (thread per entry) */
         for (int i = gtid; i < w.Ncf * 36; i += gthreads) {
@@ -961,7 +988,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
             if (lane == 0)
                 for (int a = 0; a < 6; a++) D[w.g + sl * 6 + a] = D[w.bp + (int64_t)sl * 6 + a] - acc[a];
         }
-        team_sync(team);
+        team_sync(team, s);
         BA_STAMP(5)
         bool ok2 = true;
         int it = 0;
@@ -1139,7 +1166,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
         }
         if (G > 1 && tid == 0) D[w.xl] = ok2 ? 1.0 : 0.0;
         } /* lead */
-        team_sync(team);
+        team_sync(team, s);
         if (G > 1) ok2 = __hip_atomic_load(D + w.xl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0;
         BA_STAMP(7)
         /* ---- back-substitution: xl = Dinv (bl - sum_e W_e^T x_c) (thread per point) + trial update ---- */
@@ -1175,7 +1202,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
                 for (int a = 0; a < 7; a++) D[w.poses_t + (int64_t)c * 7 + a] = D[w.poses + (int64_t)c * 7 + a];
             }
         }
-        team_sync(team);
+        team_sync(team, s);
         BA_STAMP(8)
         double tempChi = eval_chi2_partial(w, D, I, B, w.poses_t, w.pts_t, w.err_t, team);
         double scale = scale_loc;
@@ -1214,6 +1241,13 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
         st[ST_PCG_ITERS] += pcg_total;
         if (qmax == 10 || rho == 0) st[ST_TERM] = 1.0; /* OptimizationAlgorithmLevenberg returns Terminate */
     }
+    if (team.dead) {
+        if (tid == 0) st[ST_ABORT] = 1.0;
+        break;
+    }
+    if (qmax == 10 || rho == 0) break; /* uniform: terminated */
+    if (iter + 1 < n_iters) team_sync(team, s); /* the accepted estimate (written team-strided) is read edge-strided next */
+    } /* iterations of this launch */
 }
 
 /* between rounds: re-evaluate every edge at the accepted estimate, switch off edges with chi2 above
@@ -1514,7 +1548,7 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hO, std::vecto
         hI[w.con_e1 + i] = ce1[i];
         hI[w.con_e2 + i] = ce2[i];
     }
-    w.gbar = allocI(2);
+    w.gbar = allocI(4); /* two alternating arrival counters + the abort word */
     w.flags = (int64_t)hB.size();
     hB.resize(hB.size() + ((E + 15) & ~15), 0);
     for (int k = 0; k < E; k++) hB[w.flags + k] = (uint8_t)(1 | (p->huber_delta > 0 ? 2 : 0));
@@ -1769,9 +1803,12 @@ static int ba_stage(BASolver *s, BAJob &J, const BAProblem *probs, BAResult *res
 /* workgroups per window: as many as fit co-resident AND as the window's size can feed (a team member needs a few
  * hundred edges per phase to be worth its barrier) */
 static int ba_choose_team(BASolver *s, const BAJob &J, size_t dyn_bytes) {
-    int occ = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_ba_iteration, BA_T, dyn_bytes) != hipSuccess || occ < 1) occ = 1;
-    const int resident = s->cu_count * occ;
+    /* k_ba_iteration holds 256 VGPRs per lane: two waves per SIMD = exactly ONE 512-thread workgroup per CU, whatever
+       the LDS would allow.  Not asked of hipOccupancyMaxActiveBlocksPerMultiprocessor: that API can answer one block
+       per CU too high (MI355X_MICROARCH.md, correctness boundaries) and a team barrier would then wait for a workgroup
+       that is not resident. */
+    (void)dyn_bytes;
+    const int resident = s->cu_count;
     int maxE = 0;
     for (int i = 0; i < J.nwin; i++) maxE = std::max(maxE, J.wins[i].E);
     int want = s->force_team > 0 ? s->force_team : std::max(1, maxE / 768);
@@ -1838,23 +1875,25 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
     int seq = 0;
     bool halted = false;
     for (int round = 0; round < P0.n_rounds && !halted; round++) {
-        for (int it = 0; it < P0.rounds[round]; it++) {
+        /* one launch per optimize() round; per iteration only when the host has a stop flag to poll in between */
+        const int per_launch = any_stop_ptr ? 1 : std::max(P0.rounds[round], 1);
+        for (int it = 0; it < P0.rounds[round]; it += per_launch) {
             if (stopped()) { /* g2o polls the force-stop flag between iterations */
                 halted = true;
                 break;
             }
             if (s->profiling) BCHK(hipEventRecord(J.prof_ev[2 * J.prof_launches], s->stream));
-            int first = it == 0 ? 1 : 0, solver = s->solver, g = G, sq = seq++;
+            int first = it == 0 ? 1 : 0, solver = s->solver, g = G, sq = seq++, nit = std::min(per_launch, P0.rounds[round] - it);
             double tol2 = s->pcg_tol2;
             int dbg = debug;
             if (G > 1) {
                 /* a team needs all its workgroups resident at once: cooperative launch */
-                void *args[] = {&bufs, &first, &tol2, &pcg_maxit, &dbg, &solver, &dyn_doubles, &g, &sq};
+                void *args[] = {&bufs, &first, &tol2, &pcg_maxit, &dbg, &solver, &dyn_doubles, &g, &sq, &nit};
                 BCHK(hipLaunchCooperativeKernel((const void *)k_ba_iteration, dim3(nwin * G), dim3(BA_T), args,
                                                 (size_t)dyn_doubles * 8, s->stream));
             } else {
                 hipLaunchKernelGGL(k_ba_iteration, dim3(nwin), dim3(BA_T), (size_t)dyn_doubles * 8, s->stream, bufs, first, tol2,
-                                   pcg_maxit, dbg, solver, dyn_doubles, 1, sq);
+                                   pcg_maxit, dbg, solver, dyn_doubles, 1, sq, nit);
                 BCHK(hipGetLastError());
             }
             if (s->profiling) BCHK(hipEventRecord(J.prof_ev[2 * J.prof_launches + 1], s->stream));
@@ -1906,6 +1945,11 @@ static int ba_finish(BASolver *s, BAJob &J) {
         }
     });
     s->last_team = J.team;
+    for (int i = 0; i < nwin; i++)
+        if (J.pD[J.wins[i].st + ST_ABORT] != 0.0) {
+            b_err = "ba_solve: a workgroup-team barrier timed out (window results are invalid)";
+            return ORB_E_HIP;
+        }
     if (s->profiling && J.prof_launches > 0) {
         double sum = 0;
         for (int k = 0; k < J.prof_launches; k++) {
@@ -1973,6 +2017,7 @@ extern "C" int ba_solve_batch(BASolver *s, const BAProblem *probs, BAResult *res
     if (rc) return rc;
     while (s->in_flight > 0)
         if ((rc = ba_wait(s))) return rc;
+    s->next_slot = s->oldest_slot = 0; /* the synchronous path always works in slot 0: one set of buffers */
     if ((rc = ba_submit_batch(s, probs, res, nwin))) return rc;
     return ba_wait(s);
 }
