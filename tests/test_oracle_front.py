@@ -165,6 +165,52 @@ def test_resize_close_to_float_bilinear(oracle):
     assert np.all(oracle.resize_linear(const, 50, 42) == 137)
 
 
+def _resize_linear_fixed_point(src, dw, dh):
+    """independent VECTORISED numpy statement of cv::resize INTER_LINEAR on 8-bit data (OpenCV 2.4/3.x imgwarp.cpp,
+    generic path, no IPP), written from the published algorithm and not from oracle/: scale = 1 / (dst / src) in
+    double; source coordinate (d + 0.5) * scale - 0.5 cast to FLOAT, then floor and fraction; x: sx < 0 -> (0, weight
+    0), sx >= w - 1 -> (w - 1, weight 0); y: no weight clamping, the two source ROWS are clipped to the image instead;
+    weights saturate_cast<short>(w * 2048) (round half to even); horizontal pass to int32; vertical pass
+    (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2."""
+    sh, sw = src.shape
+
+    def coords(dn, sn):
+        scale = np.float64(1.0) / (np.float64(dn) / np.float64(sn))
+        f = ((np.arange(dn, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+        s0 = np.floor(f).astype(np.int64)
+        return s0, f - s0.astype(np.float32)
+
+    def weights(fr):
+        return (np.rint((np.float32(1.0) - fr) * np.float32(2048)).astype(np.int64),
+                np.rint(fr * np.float32(2048)).astype(np.int64))
+
+    x0, fx = coords(dw, sw)
+    lo, hi = x0 < 0, x0 >= sw - 1
+    x0[lo], fx[lo] = 0, 0.0
+    x0[hi], fx[hi] = sw - 1, 0.0
+    ax0, ax1 = weights(fx)
+    x1 = np.minimum(x0 + 1, sw - 1)
+    y0, fy = coords(dh, sh)
+    ay0, ay1 = weights(fy)
+    r0, r1 = np.clip(y0, 0, sh - 1), np.clip(y0 + 1, 0, sh - 1)
+    s = src.astype(np.int64)
+    H = s[:, x0] * ax0 + s[:, x1] * ax1                       # [sh, dw], int32 in OpenCV
+    v = (((ay0[:, None] * (H[r0] >> 4)) >> 16) + ((ay1[:, None] * (H[r1] >> 4)) >> 16) + 2) >> 2
+    return np.clip(v, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("sw,sh,dw,dh,seed", [(120, 100, 100, 83, 3), (640, 480, 533, 400, 4), (533, 400, 444, 333, 5),
+                                              (214, 161, 179, 134, 6), (1280, 720, 1067, 600, 7), (37, 29, 31, 24, 8)])
+def test_resize_bit_exact_against_numpy_fixed_point(oracle, sw, sh, dw, dh, seed):
+    """the oracle's bilinear resize against an independent vectorised restatement of the 11-bit fixed-point
+    algorithm: BIT-EXACT (pyramid level pairs of both BASELINE frame sizes, and odd small shapes)"""
+    rng = np.random.default_rng(seed)
+    src = rng.integers(0, 256, (sh, sw)).astype(np.uint8)
+    assert np.array_equal(oracle.resize_linear(src, dw, dh), _resize_linear_fixed_point(src, dw, dh))
+    smooth = (np.add.outer(np.arange(sh), np.arange(sw)) % 256).astype(np.uint8)
+    assert np.array_equal(oracle.resize_linear(smooth, dw, dh), _resize_linear_fixed_point(smooth, dw, dh))
+
+
 def test_blur_is_the_fixed_point_separable_kernel(oracle):
     rng = np.random.default_rng(4)
     img = rng.integers(0, 256, (37, 53)).astype(np.uint8)

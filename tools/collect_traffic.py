@@ -18,9 +18,11 @@ import glob
 import json
 import sys
 
-STAGE = {"k_copy_level0": "pyramid", "k_resize": "pyramid", "k_fast_cells": "fast", "k_fast_cells_wave": "fast", "k_quadtree": "quadtree",
+STAGE = {"k_ba_iteration": "ba_iteration", "k_pyramid": "pyramid", "k_copy_level0": "pyramid", "k_resize": "pyramid", "k_fast_cells": "fast", "k_fast_cells_wave": "fast", "k_quadtree": "quadtree",
          "k_blur": "blur", "k_describe": "describe", "k_match_knn": "match_knn", "k_match_init": "match_resolve"}
-LAUNCHES_PER_STEP = {"pyramid": 1, "fast": 1, "quadtree": 1, "blur": 1, "describe": 1, "match_knn": 1, "match_resolve": 1}
+LAUNCHES_PER_STEP = {"pyramid": 1, "fast": 1, "quadtree": 1, "blur": 1, "describe": 1, "match_knn": 1, "match_resolve": 1,
+                     "ba_iteration": 1}
+BA_BATCH = 256  # only the one-workgroup-per-window batch launches of k_ba_iteration are tallied (grid = BA_BATCH x 512 threads)
 
 
 def load(d, counter):
@@ -31,9 +33,11 @@ def load(d, counter):
         if r["Counter_Name"] != counter:
             continue
         name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+        if name == "k_ba_iteration" and int(r["Grid_Size"]) != BA_BATCH * 512:
+            continue
         if name in STAGE:
             tot[STAGE[name]] += float(r["Counter_Value"])
-            if name in ("k_copy_level0", "k_fast_cells", "k_fast_cells_wave", "k_quadtree", "k_blur", "k_describe", "k_match_knn", "k_match_init"):
+            if name in ("k_ba_iteration", "k_pyramid", "k_copy_level0", "k_fast_cells", "k_fast_cells_wave", "k_quadtree", "k_blur", "k_describe", "k_match_knn", "k_match_init"):
                 calls[STAGE[name]] += 1
     return tot, calls
 
@@ -42,8 +46,15 @@ def main():
     fetch_dir, write_dir, out, batch = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
     fetch, calls = load(fetch_dir, "FETCH_SIZE")
     write, calls_w = load(write_dir, "WRITE_SIZE")
-    res = {"_note": "HBM-side bytes per launch (one launch = one batch of %d frames); fetch doubled per the gfx950 "
-                    "FETCH_SIZE correction, write as counted" % batch, "_batch": batch}
+    res = {"_note": "HBM-side bytes per launch (one launch = one batch of %d frames; ba_iteration: one optimize() round of "
+                    "%d windows, the average of the 5- and the 10-iteration round); fetch doubled per the gfx950 "
+                    "FETCH_SIZE correction, write as counted" % (batch, BA_BATCH), "_batch": batch, "_ba_batch": BA_BATCH}
+    if len(sys.argv) > 5:  # optional: SQ summary (tools/collect_sq.py) -> VALU instructions per launch for the issue-rate view
+        sq = json.load(open(sys.argv[5]))
+        for kern, st in (("k_fast_cells_wave", "fast"), ("k_quadtree", "quadtree"), ("k_blur", "blur"), ("k_describe", "describe"),
+                         ("k_match_knn", "match_knn"), ("k_match_init", "match_resolve")):
+            if kern in sq and "SQ_INSTS_VALU" in sq[kern]:
+                res["valu_insts_" + st] = int(sq[kern]["SQ_INSTS_VALU"])
     for st in LAUNCHES_PER_STEP:
         if calls[st] == 0:
             continue
