@@ -33,6 +33,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <numeric>
 #include <string>
 #include <thread>
 #include <vector>
@@ -44,6 +45,11 @@
 #define BA_W (BA_T / 64)
 #define BA_MAX_N 1536 /* reduced system size (6 * free cameras) whose PCG vectors fit the static LDS arrays */
 #define BA_GMAX 64    /* most workgroups that may team up on one window */
+#define BA_CHUNK_E 512 /* Schur staging: edges (W records, 144 B) of one point chunk held in LDS */
+#define BA_CHUNK_P 128 /* ... and its points (Dinv 72 B, tv 24 B) */
+#define BA_CHUNK_C 4096 /* ... and its contribution list (packed local edge pairs, ints) */
+#define BA_CHUNK_B 256  /* ... and the blocks it touches (id, list start) */
+#define BA_CHUNK_DOUBLES (BA_CHUNK_E * 18 + BA_CHUNK_P * 12 + BA_CHUNK_E / 2 + BA_CHUNK_C / 2 + BA_CHUNK_B + BA_CHUNK_E / 2 + 32)
 
 static OrbErrSlot b_err; /* forwards to orb_last_error() */
 #define BCHK(expr)                                                          \
@@ -61,11 +67,16 @@ struct BAWin {
     int ch_pm;                     /* rows of the Cholesky LDS panel: 16 x the widest envelope column (tile rows below a diagonal tile) */
     double fx, fy, cx, cy, delta, chi2_thr;
     /* doubles */
-    int64_t poses, poses_t, pts, pts_t, obs, info, err, err_t, W, Y, Hpp, bp, Hll, bl, Dinv, S, g, Minv, x, xl, st;
+    int64_t poses, poses_t, pts, pts_t, obs, info, err, err_t, W, tv, Hpp, bp, Hll, bl, Dinv, S, g, Minv, x, xl, st;
     int64_t A, Linv; /* dense reduced system (np x np) and inverse diagonal blocks of its Cholesky factor */
     /* ints */
     int64_t cam, pt, pt_start, cam_start, cam_edges, slot, blk_row, blk_col, blk_diag, blk_mirror, blk_upper, blk_rowid, con_start, con_e1, con_e2;
     int64_t ch_first, ch_last; /* Cholesky envelope per 16-row tile: first tile column of tile row i (non-decreasing), last tile row that reaches tile column k */
+    /* batch path of the Schur complement: point chunks (12 ints each: edge range, point range, block range, camera
+       range, start and length of the chunk's contribution list and of its camera edge list), per chunk the blocks it touches with their contribution lists (local edge pair packed a | b << 16) and
+       the free cameras it touches with their local edge lists; nchunks == 0: list path only */
+    int nchunks, pad_;
+    int64_t ch_desc, cb_blk, cb_start, cb_con, cg_slot, cg_start, cg_edge;
     int64_t gbar;              /* ints: two arrival counters of the window's workgroup team (alternating per launch) */
     int64_t gred;              /* doubles (scratch): 2 slots x 2 values x BA_GMAX partial sums of the team */
     int64_t pcgv;              /* doubles (scratch): x, r, z, p, Ap of a PCG whose vectors exceed the LDS arrays (n > BA_MAX_N) */
@@ -75,8 +86,8 @@ struct BAWin {
 /* LM state (doubles at D[st + i]) */
 enum { ST_LAMBDA = 0, ST_NI, ST_CHI, ST_CHI0, ST_ITERS, ST_SOLVES, ST_TERM, ST_ROUND_IT, ST_HAVE_CHI0, ST_PCG_ITERS,
        ST_ABORT, /* a team barrier gave up waiting (never expected; the host turns it into an error) */
-       ST_T0, /* 10 phase timers (profile mode), 100 MHz ticks */
-       ST_COUNT = ST_T0 + 10 };
+       ST_T0, /* 10 phase timers + 6 sub-timers of the chunked Schur pass (profile mode), 100 MHz ticks */
+       ST_COUNT = ST_T0 + 24 };
 
 struct BABufs {
     double *D;
@@ -412,8 +423,48 @@ typedef double v4d __attribute__((ext_vector_type(4)));
     } while (0)
 
 __device__ int g_chol_scalar = 0; /* debug: 1 = plain loops instead of MFMA */
-__device__ __noinline__ bool ba_chol_solve(const BAWin &w, double *D, const int32_t *I, int n, double *dyn, BAShared &s) {
+
+/* the dense np x np matrix of the reduced camera system, from the block-sparse S: zero the envelope, then scatter the
+ * blocks on or above the diagonal (the only ones the Schur phase fills) TRANSPOSED -- the factorisation works on the
+ * lower triangle -- and pad the diagonal with ones.  Strided over the whole team (gtid of gthreads; rows by gwave of
+ * gwaves): disjoint writers, except that a block overwrites zeros of the first loop, hence the barrier in between
+ * (the caller supplies it as a callable: __syncthreads() or the team barrier). */
+template <class Sync>
+__device__ __forceinline__ void ba_chol_assemble(const BAWin &w, double *D, const int32_t *I, int n, int gtid, int gthreads, int gwave,
+                                                 int gwaves, Sync &&sync) {
+    const int np = (n + 15) & ~15, lane = threadIdx.x & 63;
+    double *A = D + w.A;
+    const int32_t *efirst = I + w.ch_first;
+    for (int r = gwave; r < np; r += gwaves) { /* only the envelope [first(tile row) * 16, diagonal tile] is ever read */
+        const int c0 = efirst[r >> 4] * 16, c1 = ((r >> 4) + 1) * 16;
+        for (int c = c0 + lane; c < c1; c += 64) A[(int64_t)r * np + c] = 0.0;
+    }
+    sync();
+    for (int i = gtid; i < w.nnzb * 36; i += gthreads) {
+        const int bk = i / 36, e = i - bk * 36;
+        const int br = I[w.blk_rowid + bk], bc = I[w.blk_col + bk];
+        if (bc >= br) A[(int64_t)(bc * 6 + e % 6) * np + br * 6 + e / 6] = D[w.S + i];
+    }
+    for (int i = n + gtid; i < np; i += gthreads) A[(int64_t)i * np + i] = 1.0; /* identity padding */
+}
+
+/* value of `v` in lane `src` (a compile-time constant), through two v_readlane_b32: no LDS round trip */
+__device__ __forceinline__ double lane_bcast(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+__device__ __noinline__ bool ba_chol_solve(const BAWin &w, double *D, const int32_t *I, int n, double *dyn, BAShared &s, int debug) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); /* uniform: scalar unit */
+    unsigned long long tp = debug ? __builtin_amdgcn_s_memrealtime() : 0ull;
+#define CH_STAMP(k)                                                         \
+    if (debug) {                                                            \
+        __syncthreads();                                                    \
+        if (tid == 0) {                                                     \
+            const unsigned long long tn = __builtin_amdgcn_s_memrealtime(); \
+            D[w.st + ST_T0 + 16 + (k)] += (double)(tn - tp);                \
+            tp = tn;                                                        \
+        }                                                                   \
+    }
     const int np = (n + 15) & ~15, nb = np >> 4;
     double *A = D + w.A;
     double *Li = D + w.Linv;
@@ -421,69 +472,67 @@ __device__ __noinline__ bool ba_chol_solve(const BAWin &w, double *D, const int3
     double *sd = P + (size_t)w.ch_pm * CH_LD; /* diagonal block, 16 x CH_LD   */
     double *sl = sd + 16 * CH_LD;           /* its inverse, 16 x CH_LD      */
     double *z = sl + 16 * CH_LD;            /* right-hand side / solution   */
-    /* ---- assemble the dense matrix from the block-sparse S ---- */
     const int32_t *efirst = I + w.ch_first, *elast = I + w.ch_last;
-    for (int r = wave; r < np; r += BA_W) { /* only the envelope [first(tile row) * 16, diagonal tile] is ever read */
-        const int c0 = efirst[r >> 4] * 16, c1 = ((r >> 4) + 1) * 16;
-        for (int c = c0 + lane; c < c1; c += 64) A[(int64_t)r * np + c] = 0.0;
-    }
     if (tid == 0) s.bc[0] = 0.0;
     __syncthreads();
-    for (int i = tid; i < w.nnzb * 36; i += BA_T) {
-        const int bk = i / 36, e = i - bk * 36;
-        const int r = I[w.blk_rowid + bk] * 6 + e / 6, c = I[w.blk_col + bk] * 6 + e % 6;
-        A[(int64_t)r * np + c] = D[w.S + i];
-    }
-    for (int i = n + tid; i < np; i += BA_T) A[(int64_t)i * np + i] = 1.0; /* identity padding */
-    __syncthreads();
+    CH_STAMP(0)
     /* ---- factorisation ---- */
     for (int kb = 0; kb < nb; kb++) {
         const int m = elast[kb] - kb; /* tile rows below the diagonal that reach column kb */
-        if (tid < 256) sd[(tid >> 4) * CH_LD + (tid & 15)] = A[(int64_t)(kb * 16 + (tid >> 4)) * np + kb * 16 + (tid & 15)];
-        __syncthreads();
+        /* diagonal 16 x 16 tile: Cholesky factor and its inverse by ONE wavefront in registers -- lane r < 16 holds row r,
+           a pivot or a column entry travels by v_readlane (lane_bcast), every loop is unrolled so that all register
+           indices are static.  Same operations in the same order as the textbook right-looking loop
+           (a[i][k] -= l[i][j] * l[k][j] for j < k <= i), so the factor is bit-identical to the LDS version it replaces,
+           at a third of its time (16 columns x 3 LDS round trips per column before). */
         if (wave == 0) {
+            const int rl = lane & 15;
+            double a[16];
+            {
+                const double *Ar = A + (int64_t)(kb * 16 + rl) * np + kb * 16;
+#pragma unroll
+                for (int k = 0; k < 16; k++) a[k] = Ar[k];
+            }
             bool bad = false;
+#pragma unroll
             for (int j = 0; j < 16; j++) {
-                double ajj = sd[j * CH_LD + j];
+                double ajj = lane_bcast(a[j], j);
                 if (!(ajj > 0.0) || !isfinite(ajj)) {
                     bad = true;
                     ajj = 1.0;
                 }
                 const double pv = sqrt(ajj);
-                CH_WAVE_SYNC();
-                if (lane == j) sd[j * CH_LD + j] = pv;
-                if (lane > j && lane < 16) sd[lane * CH_LD + j] = sd[lane * CH_LD + j] / pv;
-                CH_WAVE_SYNC();
-                for (int e = lane; e < 256; e += 64) {
-                    const int i = e >> 4, k = e & 15;
-                    if (k > j && i >= k) sd[i * CH_LD + k] -= sd[i * CH_LD + j] * sd[k * CH_LD + j];
-                }
-                CH_WAVE_SYNC();
-            }
-            if (lane < 16) { /* column `lane` of L^-1 by forward substitution (static register indices) */
-                const int c = lane;
-                double x[16];
+                a[j] = (rl == j) ? pv : a[j] / pv; /* rows above j hold don't-care values in column j */
 #pragma unroll
-                for (int i = 0; i < 16; i++) x[i] = 0.0;
+                for (int k = j + 1; k < 16; k++) {
+                    const double lkj = lane_bcast(a[j], k);
+                    a[k] -= a[j] * lkj;
+                }
+            }
+            /* column rl of L^-1 by forward substitution: x[i] = (delta - sum_{k<i} l[i][k] x[k]) / l[i][i] */
+            double x[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                double v = (i == rl) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                    if (k < i) v -= lane_bcast(a[k], i) * x[k];
+                const double lii = lane_bcast(a[i], i);
+                x[i] = (i >= rl) ? v / lii : 0.0;
+            }
+            if (lane < 16) {
+                double *Ar = A + (int64_t)(kb * 16 + rl) * np + kb * 16;
+#pragma unroll
+                for (int c = 0; c < 16; c++) Ar[c] = (c <= rl) ? a[c] : 0.0;
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
-                    double v = (i == c) ? 1.0 : 0.0;
-#pragma unroll
-                    for (int k = 0; k < 16; k++)
-                        if (k < i) v -= sd[i * CH_LD + k] * x[k];
-                    x[i] = (i >= c) ? v / sd[i * CH_LD + i] : 0.0;
+                    sl[i * CH_LD + rl] = x[i];           /* (x[i] is 0 above the diagonal) */
+                    Li[kb * 256 + i * 16 + rl] = x[i];
                 }
-#pragma unroll
-                for (int i = 0; i < 16; i++) sl[i * CH_LD + c] = x[i];
             }
             if (bad && lane == 0) s.bc[0] = 1.0;
         }
         __syncthreads();
-        if (tid < 256) {
-            const int r = tid >> 4, c = tid & 15;
-            A[(int64_t)(kb * 16 + r) * np + kb * 16 + c] = (c <= r) ? sd[r * CH_LD + c] : 0.0;
-            Li[kb * 256 + tid] = (c <= r) ? sl[r * CH_LD + c] : 0.0;
-        }
+        CH_STAMP(2)
         /* panel: L_i = A_i * L11^-T */
         if (g_chol_scalar) {
             for (int e = tid; e < m * 256; e += BA_T) {
@@ -516,6 +565,7 @@ __device__ __noinline__ bool ba_chol_solve(const BAWin &w, double *D, const int3
             }
         }
         __syncthreads();
+        CH_STAMP(3)
         /* trailing update: A[i][j] -= L_i L_j^T for kb < j <= i */
         const int ntile = m * (m + 1) / 2;
         if (g_chol_scalar) {
@@ -547,6 +597,7 @@ __device__ __noinline__ bool ba_chol_solve(const BAWin &w, double *D, const int3
             for (int r = 0; r < 4; r++) C[(int64_t)4 * r * np] = c4[r];
         }
         __syncthreads();
+        CH_STAMP(4)
     }
     const bool ok = s.bc[0] == 0.0;
     /* ---- forward substitution L y = g ---- */
@@ -568,6 +619,7 @@ __device__ __noinline__ bool ba_chol_solve(const BAWin &w, double *D, const int3
         }
         __syncthreads();
     }
+    CH_STAMP(5)
     /* ---- backward substitution L^T x = y ---- */
     for (int kb = nb - 1; kb >= 0; kb--) {
         double v = 0.0;
@@ -586,7 +638,292 @@ __device__ __noinline__ bool ba_chol_solve(const BAWin &w, double *D, const int3
     }
     for (int i = tid; i < n; i += BA_T) D[w.x + i] = ok ? z[i] : 0.0;
     __syncthreads();
+    CH_STAMP(6)
     return ok;
+}
+
+/* Schur complement, batch path (one workgroup per window).
+ * The points are laid out sorted by their first free camera, so a chunk of consecutive points (<= BA_CHUNK_E edges,
+ * <= BA_CHUNK_P points) touches a compact band of S.  Per chunk: the W records of its edges, the Dinv / tv of its
+ * points and the edge -> point map are streamed ONCE, coalesced, into the dynamic LDS region (free until the Cholesky
+ * needs it) -- fetched into registers while the previous chunk is still being worked on, so the memory latency hides
+ * behind the block products; every (block, chunk) pair has one owner, a 4-lane group, that adds up the chunk's
+ * contributions to that block from LDS in list order (Y = W Dinv formed in registers) and subtracts the sum from the
+ * block in memory (the block's current value is requested before the products start); chunks follow each other behind
+ * a barrier.  Fixed order, no atomics.  g = bp - sum W tv rides along the same way with one owner per
+ * (camera, chunk).  HBM sees each W record once per solve instead of once per block it takes part in (the
+ * list-based version moved 5.7x the algorithmic bytes with 256 windows in flight).
+ * A separate function with its own register allocation (inlined, the live doubles of the block products pushed the
+ * whole iteration kernel from 39 to 83 spilled VGPRs). */
+#define BA_CH_WPT ((BA_CHUNK_E * 9 + BA_T - 1) / BA_T)  /* double2 of W per thread */
+#define BA_CH_DPT ((BA_CHUNK_P * 9 + BA_T - 1) / BA_T)  /* doubles of Dinv per thread */
+#define BA_CH_CPT (BA_CHUNK_C / BA_T)                   /* contribution-list ints per thread */
+/* sum of 36 per-lane partials over the 16 lanes of a group by recursive halving: at offset 8, 4, 2, 1 a lane keeps
+ * the half of its values that its lane bit selects and adds the partner's copy of that half -- 24 + 12 + 6 + 3 = 45
+ * exchanges instead of the 144 of four full butterflies (each f64 exchange is two LDS-crossbar permutes).  Lane q ends
+ * up with the totals of entries 3q, 3q+1, 3q+2 (lanes 12..15: padding). */
+__device__ __forceinline__ void group16_reduce36(const double *acc, int l16, double &o0, double &o1, double &o2) {
+    double a24[24], a12[12], a6[6];
+    const bool h8 = l16 & 8, h4 = l16 & 4, h2 = l16 & 2, h1 = l16 & 1;
+#pragma unroll
+    for (int i = 0; i < 24; i++) {
+        const double lo = acc[i], hi = (24 + i < 36) ? acc[24 + i] : 0.0;
+        a24[i] = (h8 ? hi : lo) + __shfl_xor(h8 ? lo : hi, 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) a12[i] = (h4 ? a24[12 + i] : a24[i]) + __shfl_xor(h4 ? a24[i] : a24[12 + i], 4);
+#pragma unroll
+    for (int i = 0; i < 6; i++) a6[i] = (h2 ? a12[6 + i] : a12[i]) + __shfl_xor(h2 ? a12[i] : a12[6 + i], 2);
+    o0 = (h1 ? a6[3] : a6[0]) + __shfl_xor(h1 ? a6[0] : a6[3], 1);
+    o1 = (h1 ? a6[4] : a6[1]) + __shfl_xor(h1 ? a6[1] : a6[4], 1);
+    o2 = (h1 ? a6[5] : a6[2]) + __shfl_xor(h1 ? a6[2] : a6[5], 1);
+}
+
+__device__ __noinline__ void ba_schur_chunked(const BAWin &w, double *D, const int32_t *I, double *ba_dyn, int debug) {
+#pragma clang fp contract(fast) /* the block products as FMAs: half the f64 instructions; estimates are compared at 1e-5 */
+    const int tid = threadIdx.x;
+    unsigned long long tp = debug ? __builtin_amdgcn_s_memrealtime() : 0ull;
+#define SCH_STAMP(k)                                                        \
+    if (debug) {                                                            \
+        __syncthreads();                                                    \
+        if (tid == 0) {                                                     \
+            const unsigned long long tn = __builtin_amdgcn_s_memrealtime(); \
+            D[w.st + ST_T0 + 10 + (k)] += (double)(tn - tp);                \
+            tp = tn;                                                        \
+        }                                                                   \
+    }
+    /* LDS tiles of one chunk */
+    double *sW = ba_dyn, *sD = sW + BA_CHUNK_E * 18, *sT = sD + BA_CHUNK_P * 9;
+    int32_t *sP = (int32_t *)(sT + BA_CHUNK_P * 3); /* edge -> local point                        */
+    int32_t *sC = sP + BA_CHUNK_E;                  /* contribution lists (a | b << 16)            */
+    int32_t *sB = sC + BA_CHUNK_C;                  /* blocks touched                              */
+    int32_t *sBS = sB + BA_CHUNK_B;                 /* their list starts, relative to the chunk's  */
+    int32_t *sG = sBS + BA_CHUNK_B + 8;             /* local edges by free camera                  */
+    const int grp = tid >> 4, l16 = tid & 15;
+    double2 rW[BA_CH_WPT];
+    double rD[BA_CH_DPT], rT;
+    int32_t rP, rC[BA_CH_CPT], rB, rBS, rG;
+    static_assert(BA_CHUNK_E <= BA_T && BA_CHUNK_P * 3 <= BA_T && BA_CHUNK_B + 1 <= BA_T && BA_CHUNK_C % BA_T == 0,
+                  "one element per thread for the small tiles");
+    auto fetch = [&](int ch) { /* chunk ch -> registers, every load issued back to back */
+        const int32_t *cd = I + w.ch_desc + ch * 12;
+        const int e0 = cd[0], ne = cd[1] - cd[0], p0 = cd[2], npnt = cd[3] - cd[2], cb0 = cd[4], ncb = cd[5] - cd[4];
+        const int c0 = cd[8], nc = cd[9], g0 = cd[10], ng = cd[11];
+        const double2 *src = (const double2 *)(D + w.W + (int64_t)e0 * 18); /* 144-B records: 16-B aligned */
+#pragma unroll
+        for (int k = 0; k < BA_CH_WPT; k++) {
+            const int i = tid + k * BA_T;
+            rW[k] = i < ne * 9 ? src[i] : double2{0.0, 0.0};
+        }
+#pragma unroll
+        for (int k = 0; k < BA_CH_DPT; k++) {
+            const int i = tid + k * BA_T;
+            rD[k] = i < npnt * 9 ? D[w.Dinv + (int64_t)p0 * 9 + i] : 0.0;
+        }
+        rT = tid < npnt * 3 ? D[w.tv + (int64_t)p0 * 3 + tid] : 0.0;
+        rP = tid < ne ? I[w.pt + e0 + tid] - p0 : 0;
+#pragma unroll
+        for (int k = 0; k < BA_CH_CPT; k++) {
+            const int i = tid + k * BA_T;
+            rC[k] = i < nc ? I[w.cb_con + c0 + i] : 0;
+        }
+        rB = tid < ncb ? I[w.cb_blk + cb0 + tid] : 0;
+        rBS = tid <= ncb ? I[w.cb_start + cb0 + tid] - c0 : 0;
+        rG = tid < ng ? I[w.cg_edge + g0 + tid] : 0;
+    };
+    auto commit = [&]() { /* registers -> LDS tiles */
+#pragma unroll
+        for (int k = 0; k < BA_CH_WPT; k++) {
+            const int i = tid + k * BA_T;
+            if (i < BA_CHUNK_E * 9) ((double2 *)sW)[i] = rW[k];
+        }
+#pragma unroll
+        for (int k = 0; k < BA_CH_DPT; k++) {
+            const int i = tid + k * BA_T;
+            if (i < BA_CHUNK_P * 9) sD[i] = rD[k];
+        }
+        if (tid < BA_CHUNK_P * 3) sT[tid] = rT;
+        if (tid < BA_CHUNK_E) sP[tid] = rP;
+#pragma unroll
+        for (int k = 0; k < BA_CH_CPT; k++) sC[tid + k * BA_T] = rC[k];
+        if (tid < BA_CHUNK_B) sB[tid] = rB;
+        if (tid <= BA_CHUNK_B) sBS[tid] = rBS;
+        if (tid < BA_CHUNK_E) sG[tid] = rG;
+    };
+    fetch(0);
+    for (int ch = 0; ch < w.nchunks; ch++) {
+        const int32_t *cd = I + w.ch_desc + ch * 12;
+        const int ncb = cd[5] - cd[4], cg0 = cd[6], ncg = cd[7] - cd[6], g0 = cd[10];
+        commit();
+        __syncthreads();
+        SCH_STAMP(0)
+        if (ch + 1 < w.nchunks) fetch(ch + 1); /* in flight during the products below */
+        SCH_STAMP(1)
+        /* blocks: group g takes blocks g, g + 32, ... of the chunk's list (sorted heaviest first on the host) */
+        for (int u = grp; u < ncb; u += BA_T / 16) {
+            const int bk = sB[u], k0 = sBS[u], k1 = sBS[u + 1];
+            /* lanes 0..11 of the group own 3 entries of the 6 x 6 block each for the update; requested now, used last */
+            double *Sb = D + w.S + (int64_t)bk * 36 + (l16 < 12 ? l16 : 0) * 3;
+            const double sb0 = Sb[0], sb1 = Sb[1], sb2 = Sb[2];
+            double acc[36];
+#pragma unroll
+            for (int i = 0; i < 36; i++) acc[i] = 0.0;
+            for (int k = k0 + l16; k < k1; k += 16) {
+                const uint32_t ab = (uint32_t)sC[k];
+                const int a = ab & 0xFFFF, b = ab >> 16;
+                const double *Wa = sW + a * 18, *Wb = sW + b * 18, *Iv = sD + sP[a] * 9;
+                double y[18], ww[18];
+#pragma unroll
+                for (int r = 0; r < 6; r++) {
+                    const double w0 = Wa[r * 3], w1 = Wa[r * 3 + 1], w2 = Wa[r * 3 + 2];
+                    y[r * 3] = w0 * Iv[0] + w1 * Iv[3] + w2 * Iv[6];
+                    y[r * 3 + 1] = w0 * Iv[1] + w1 * Iv[4] + w2 * Iv[7];
+                    y[r * 3 + 2] = w0 * Iv[2] + w1 * Iv[5] + w2 * Iv[8];
+                }
+#pragma unroll
+                for (int i = 0; i < 18; i++) ww[i] = Wb[i];
+#pragma unroll
+                for (int r = 0; r < 6; r++)
+#pragma unroll
+                    for (int c = 0; c < 6; c++)
+                        acc[r * 6 + c] += y[r * 3] * ww[c * 3] + y[r * 3 + 1] * ww[c * 3 + 1] + y[r * 3 + 2] * ww[c * 3 + 2];
+            }
+            double d0, d1, d2;
+            group16_reduce36(acc, l16, d0, d1, d2); /* lane q now holds the totals of entries 3q .. 3q+2 */
+            if (l16 < 12) {
+                Sb[0] = sb0 - d0;
+                Sb[1] = sb1 - d1;
+                Sb[2] = sb2 - d2;
+            }
+        }
+        SCH_STAMP(2)
+        /* g: group g takes cameras g, g + 32, ... of the chunk */
+        for (int u = grp; u < ncg; u += BA_T / 16) {
+            const int sl = I[w.cg_slot + cg0 + u];
+            const int k0 = I[w.cg_start + cg0 + u] - g0, k1 = I[w.cg_start + cg0 + u + 1] - g0;
+            double acc[6] = {0, 0, 0, 0, 0, 0};
+            for (int k = k0 + l16; k < k1; k += 16) {
+                const int a = sG[k];
+                const double *Wa = sW + a * 18, *t = sT + sP[a] * 3;
+                const double t0 = t[0], t1 = t[1], t2 = t[2];
+#pragma unroll
+                for (int r = 0; r < 6; r++) acc[r] += Wa[r * 3] * t0 + Wa[r * 3 + 1] * t1 + Wa[r * 3 + 2] * t2;
+            }
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                double v = acc[r];
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                acc[r] = v;
+            }
+            if (l16 == 0) {
+#pragma unroll
+                for (int r = 0; r < 6; r++) D[w.g + sl * 6 + r] -= acc[r];
+            }
+        }
+        __syncthreads(); /* the next chunk overwrites the LDS tiles and may touch the same blocks */
+        SCH_STAMP(3)
+    }
+}
+
+__device__ __noinline__ void ba_schur_lists(const BAWin &w, double *D, const int32_t *I, int gwave, int gwaves) {
+    const int lane = threadIdx.x & 63;
+    /* ---- TEAM PATH (one window over G workgroups) and windows with a point too large for a chunk: every
+       block on or above the diagonal has one owner for the whole solve, a 16-lane group, that walks the block's
+       contribution list (edge pairs of the points both cameras see) with W and Dinv gathered from memory --
+       a single window's 8 MB stay in L2 / Infinity Cache.  Four blocks per wavefront, the edge ids of the NEXT
+       contribution fetched ahead of the operand loads of the current one. ---- */
+    for (int u0 = gwave * 4; u0 < w.nub; u0 += gwaves * 4) {
+        const int sub = lane >> 4, l16 = lane & 15;
+        const int bk = (u0 + sub < w.nub) ? I[w.blk_upper + u0 + sub] : w.nnzb; /* upper blocks only */
+        double acc[36];
+#pragma unroll
+        for (int i = 0; i < 36; i++) acc[i] = 0.0;
+        if (bk < w.nnzb) {
+            const int k0 = I[w.con_start + bk], k1 = I[w.con_start + bk + 1];
+            int kq = k0 + l16;
+            int e1n = kq < k1 ? I[w.con_e1 + kq] : 0, e2n = kq < k1 ? I[w.con_e2 + kq] : 0;
+            int pn = kq < k1 ? I[w.pt + e1n] : 0;
+            for (int k = kq; k < k1; k += 16) {
+                const int e1 = e1n, e2 = e2n, pp = pn;
+                if (k + 16 < k1) {
+                    e1n = I[w.con_e1 + k + 16];
+                    e2n = I[w.con_e2 + k + 16];
+                    pn = I[w.pt + e1n];
+                }
+                const double2 *W1 = (const double2 *)(D + w.W + (int64_t)e1 * 18); /* 144-B records */
+                const double2 *W2 = (const double2 *)(D + w.W + (int64_t)e2 * 18);
+                const double *Iv = D + w.Dinv + (int64_t)pp * 9;
+                double w1[18], ww[18], iv[9];
+#pragma unroll
+                for (int i = 0; i < 9; i++) {
+                    const double2 a2 = W1[i], b2 = W2[i];
+                    w1[2 * i] = a2.x;
+                    w1[2 * i + 1] = a2.y;
+                    ww[2 * i] = b2.x;
+                    ww[2 * i + 1] = b2.y;
+                    iv[i] = Iv[i];
+                }
+                double y[18];
+#pragma unroll
+                for (int r = 0; r < 6; r++) {
+                    y[r * 3] = w1[r * 3] * iv[0] + w1[r * 3 + 1] * iv[3] + w1[r * 3 + 2] * iv[6];
+                    y[r * 3 + 1] = w1[r * 3] * iv[1] + w1[r * 3 + 1] * iv[4] + w1[r * 3 + 2] * iv[7];
+                    y[r * 3 + 2] = w1[r * 3] * iv[2] + w1[r * 3 + 1] * iv[5] + w1[r * 3 + 2] * iv[8];
+                }
+#pragma unroll
+                for (int r = 0; r < 6; r++)
+#pragma unroll
+                    for (int c = 0; c < 6; c++)
+                        acc[r * 6 + c] += y[r * 3] * ww[c * 3] + y[r * 3 + 1] * ww[c * 3 + 1] + y[r * 3 + 2] * ww[c * 3 + 2];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 36; i++) {
+            double v = acc[i];
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            acc[i] = v;
+        }
+        if (l16 == 0 && bk < w.nnzb) {
+#pragma unroll
+            for (int i = 0; i < 36; i++) D[w.S + (int64_t)bk * 36 + i] -= acc[i]; /* sole owner: no race */
+        }
+    }
+}
+
+__device__ __noinline__ void ba_g_lists(const BAWin &w, double *D, const int32_t *I, int gwave, int gwaves) {
+    const int lane = threadIdx.x & 63;
+    /* g = bp - sum_e W_e tv : one wavefront per free camera, lanes over its edges (independent gathers) */
+    for (int sl = gwave; sl < w.Ncf; sl += gwaves) {
+        const int cam = I[w.blk_row + w.Ncf + 1 + sl]; /* slot -> camera (stored behind the row starts) */
+        const int k0 = I[w.cam_start + cam], k1 = I[w.cam_start + cam + 1];
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        for (int k = k0 + lane; k < k1; k += 64) {
+            const int e = I[w.cam_edges + k];
+            const double2 *We = (const double2 *)(D + w.W + (int64_t)e * 18);
+            const double *tp = D + w.tv + (int64_t)I[w.pt + e] * 3;
+            const double b0 = tp[0], b1 = tp[1], b2 = tp[2];
+            double y[18];
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                const double2 t = We[i];
+                y[2 * i] = t.x;
+                y[2 * i + 1] = t.y;
+            }
+#pragma unroll
+            for (int a = 0; a < 6; a++) acc[a] += y[a * 3] * b0 + y[a * 3 + 1] * b1 + y[a * 3 + 2] * b2;
+        }
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+            double v = acc[a];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            acc[a] = v;
+        }
+        if (lane == 0)
+            for (int a = 0; a < 6; a++) D[w.g + sl * 6 + a] -= acc[a];
+    }
 }
 
 /* PCG on S x = g for a reduced system whose vectors do not fit the LDS arrays (more than 256 free cameras AND an
@@ -849,7 +1186,9 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
     int qmax = 0;
     int solves = 0, pcg_total = 0;
     do {
-        /* ---- Dinv = (Hll + lambda I)^-1, Y = W Dinv (thread per point) ---- */
+        /* ---- Dinv = (Hll + lambda I)^-1 and tv = Dinv bl (thread per point).  Y = W Dinv is never stored: the Schur
+           products form it in registers from W and Dinv (54 FMAs per contribution against a 144-byte record written,
+           read back ~6 times and mostly missing every cache when 256 windows run at once) ---- */
         for (int p = gtid; p < w.Np; p += gthreads) {
             double Dm[9];
             for (int i = 0; i < 9; i++) Dm[i] = D[w.Hll + (int64_t)p * 9 + i];
@@ -870,136 +1209,57 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
             Iv[7] = (Dm[1] * Dm[6] - Dm[0] * Dm[7]) * id;
             Iv[8] = (Dm[0] * Dm[4] - Dm[1] * Dm[3]) * id;
             for (int i = 0; i < 9; i++) D[w.Dinv + (int64_t)p * 9 + i] = Iv[i];
+            const double b0 = D[w.bl + (int64_t)p * 3], b1 = D[w.bl + (int64_t)p * 3 + 1], b2 = D[w.bl + (int64_t)p * 3 + 2];
+            for (int a = 0; a < 3; a++) D[w.tv + (int64_t)p * 3 + a] = Iv[a * 3] * b0 + Iv[a * 3 + 1] * b1 + Iv[a * 3 + 2] * b2;
         }
-        team_sync(team, s);
-        /* Y = W Dinv, one thread per (edge, row of W): neighbouring threads touch neighbouring 24-B rows */
-        for (int t = gtid; t < w.E * 6; t += gthreads) {
-            const int e = t / 6, a = t - e * 6;
-            const double *Wr = D + w.W + (int64_t)e * 18 + a * 3;
-            const double *Iv = D + w.Dinv + (int64_t)I[w.pt + e] * 9;
-            const double w0 = Wr[0], w1 = Wr[1], w2 = Wr[2];
-            double *Yr = D + w.Y + (int64_t)e * 18 + a * 3;
-            Yr[0] = w0 * Iv[0] + w1 * Iv[3] + w2 * Iv[6];
-            Yr[1] = w0 * Iv[1] + w1 * Iv[4] + w2 * Iv[7];
-            Yr[2] = w0 * Iv[2] + w1 * Iv[5] + w2 * Iv[8];
-        }
-        team_sync(team, s);
-        BA_STAMP(3)
-        /* ---- S = Hpp + lambda I - sum Y W^T : one wavefront per non-zero 6x6 block.  Each LANE takes whole
-           contributions (stride 64: 64 independent Y/W gathers in flight), accumulates its own 6x6 partial in
-           registers, and the 36 partials are summed across the wavefront with shuffles -- fixed order, no
-           atomics. ---- */
-        /* four blocks per wavefront: 16 lanes per block (16 independent Y/W gathers in flight per block, 64 per
-           wave), so the per-block reduction is a 4-step butterfly inside a 16-lane row instead of 6 steps over
-           the whole wave */
-        for (int u0 = gwave * 4; u0 < w.nub; u0 += gwaves * 4) {
-            const int sub = lane >> 4, l16 = lane & 15;
-            const int bk = (u0 + sub < w.nub) ? I[w.blk_upper + u0 + sub] : w.nnzb; /* upper blocks only */
-            double acc[36];
-#pragma unroll
-            for (int i = 0; i < 36; i++) acc[i] = 0.0;
-            if (bk < w.nnzb) {
-                const int k0 = I[w.con_start + bk], k1 = I[w.con_start + bk + 1];
-                /* the edge ids of the NEXT contribution are fetched before the 36 operand loads of the current one,
-                   so that the index round trip hides behind the data round trip instead of preceding it */
-                int kq = k0 + l16;
-                int e1n = kq < k1 ? I[w.con_e1 + kq] : 0, e2n = kq < k1 ? I[w.con_e2 + kq] : 0;
-                for (int k = kq; k < k1; k += 16) {
-                    const int e1 = e1n, e2 = e2n;
-                    if (k + 16 < k1) {
-                        e1n = I[w.con_e1 + k + 16];
-                        e2n = I[w.con_e2 + k + 16];
-                    }
-                    const double2 *Y1 = (const double2 *)(D + w.Y + (int64_t)e1 * 18); /* 144-B records */
-                    const double2 *W2 = (const double2 *)(D + w.W + (int64_t)e2 * 18);
-                    double y[18], ww[18];
-#pragma unroll
-                    for (int i = 0; i < 9; i++) {
-                        const double2 a2 = Y1[i], b2 = W2[i];
-                        y[2 * i] = a2.x;
-                        y[2 * i + 1] = a2.y;
-                        ww[2 * i] = b2.x;
-                        ww[2 * i + 1] = b2.y;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 6; r++)
-#pragma unroll
-                        for (int c = 0; c < 6; c++)
-                            acc[r * 6 + c] += y[r * 3] * ww[c * 3] + y[r * 3 + 1] * ww[c * 3 + 1] + y[r * 3 + 2] * ww[c * 3 + 2];
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 36; i++) {
-                double v = acc[i];
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
-                acc[i] = v;
-            }
-            if (l16 == 0 && bk < w.nnzb) {
-#pragma unroll
-                for (int i = 0; i < 36; i++) D[w.S + (int64_t)bk * 36 + i] = -acc[i];
-            }
-        }
-        team_sync(team, s);
-        /* S is symmetric: only blocks on or above the diagonal carry contribution lists; the others are the
-           transposes of their mirrors */
+        /* S starts as Hpp + lambda I on its diagonal blocks and zero elsewhere, g as bp: the Schur products are
+           subtracted from them below (disjoint writers, no barrier needed between the two loops) */
         for (int i = gtid; i < w.nnzb * 36; i += gthreads) {
             const int bk = i / 36, e = i - bk * 36;
-            const int mk = I[w.blk_mirror + bk];
-            if (mk < bk) D[w.S + i] = D[w.S + (int64_t)mk * 36 + (e % 6) * 6 + e / 6];
+            const int sl = I[w.blk_rowid + bk];
+            double v = 0.0;
+            if (I[w.blk_col + bk] == sl) {
+                v = D[w.Hpp + (int64_t)sl * 36 + e];
+                if (e % 7 == 0) v += lambda;
+            }
+            D[w.S + i] = v;
         }
+        for (int i = gtid; i < w.Ncf * 6; i += gthreads) D[w.g + i] = D[w.bp + i];
         team_sync(team, s);
-        BA_STAMP(4)
-        /* diagonal blocks: + Hpp + lambda I (thread per entry) */
-        for (int i = gtid; i < w.Ncf * 36; i += gthreads) {
-            const int sl = i / 36, e = i - sl * 36;
-            double v = D[w.Hpp + i];
-            if (e % 7 == 0) v += lambda;
-            D[w.S + (int64_t)I[w.blk_diag + sl] * 36 + e] += v;
-        }
-        /* g = bp - sum_e Y_e bl : one wavefront per free camera, lanes over its edges (independent gathers),
-           six shuffle reductions */
-        for (int sl = gwave; sl < w.Ncf; sl += gwaves) {
-            const int cam = I[w.blk_row + w.Ncf + 1 + sl]; /* slot -> camera (stored behind the row starts) */
-            const int k0 = I[w.cam_start + cam], k1 = I[w.cam_start + cam + 1];
-            double acc[6] = {0, 0, 0, 0, 0, 0};
-            for (int k = k0 + lane; k < k1; k += 64) {
-                const int e = I[w.cam_edges + k];
-                const double2 *Ye = (const double2 *)(D + w.Y + (int64_t)e * 18);
-                const double *blp = D + w.bl + (int64_t)I[w.pt + e] * 3;
-                const double b0 = blp[0], b1 = blp[1], b2 = blp[2];
-                double y[18];
-#pragma unroll
-                for (int i = 0; i < 9; i++) {
-                    const double2 t = Ye[i];
-                    y[2 * i] = t.x;
-                    y[2 * i + 1] = t.y;
-                }
-#pragma unroll
-                for (int a = 0; a < 6; a++) acc[a] += y[a * 3] * b0 + y[a * 3 + 1] * b1 + y[a * 3 + 2] * b2;
-            }
-#pragma unroll
-            for (int a = 0; a < 6; a++) {
-                double v = acc[a];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-                acc[a] = v;
-            }
-            if (lane == 0)
-                for (int a = 0; a < 6; a++) D[w.g + sl * 6 + a] = D[w.bp + (int64_t)sl * 6 + a] - acc[a];
+        BA_STAMP(3)
+        if (w.nchunks > 0 && G == 1) {
+            ba_schur_chunked(w, D, I, ba_dyn, debug);
+            BA_STAMP(4)
+        } else {
+            ba_schur_lists(w, D, I, gwave, gwaves);
+            BA_STAMP(4)
+            ba_g_lists(w, D, I, gwave, gwaves);
         }
         team_sync(team, s);
         BA_STAMP(5)
+        const int np_ = (n + 15) & ~15;
+        const bool use_chol = solver == 1 && n > 0 && w.ch_pm > 0 && (w.ch_pm * CH_LD + 2 * 16 * CH_LD + np_) <= dyn_doubles;
+        if (!use_chol || debug > 1) {
+            /* the Cholesky reads the upper blocks only; PCG (and the debug residual) need the full symmetric S */
+            for (int i = gtid; i < w.nnzb * 36; i += gthreads) {
+                const int bk = i / 36, e = i - bk * 36;
+                const int mk = I[w.blk_mirror + bk];
+                if (mk < bk) D[w.S + i] = D[w.S + (int64_t)mk * 36 + (e % 6) * 6 + e / 6];
+            }
+            team_sync(team, s);
+        }
+        if (use_chol) { /* dense matrix of the reduced system: assembled by the whole team */
+            ba_chol_assemble(w, D, I, n, gtid, gthreads, gwave, gwaves, [&] { team_sync(team, s); });
+            team_sync(team, s);
+        }
         bool ok2 = true;
         int it = 0;
         if (lead) { /* the linear solve runs on the team's first workgroup; the others wait at the barrier below */
         /* linear solver of the reduced camera system: dense blocked Cholesky (MFMA f64) when its LDS panel fits,
            PCG otherwise / on request */
-        const int np_ = (n + 15) & ~15;
-        const bool use_chol = solver == 1 && n > 0 && w.ch_pm > 0 && (w.ch_pm * CH_LD + 2 * 16 * CH_LD + np_) <= dyn_doubles;
         if (use_chol) {
             BA_STAMP(5)
-            ok2 = ba_chol_solve(w, D, I, n, ba_dyn, s);
+            ok2 = ba_chol_solve(w, D, I, n, ba_dyn, s, debug);
             solves++;
             if (debug > 1) { /* residual of the direct solve against the block-sparse S */
                 double r2 = 0, g2 = 0;
@@ -1295,6 +1555,7 @@ struct BAPiece {
 struct HostWin {
     BAWin w;
     std::vector<int> perm; /* sorted edge -> caller's edge index */
+    std::vector<int> rank; /* caller's point -> position in the device layout */
 };
 /* Layout of a batch in the double buffer: [ outputs of every window | inputs of every window | scratch ].  The
  * output region (poses, points, LM state) is what comes back, as ONE download; inputs only go up; scratch never
@@ -1303,16 +1564,19 @@ static int64_t BAWin::*const kOutDFields[] = {&BAWin::poses, &BAWin::pts, &BAWin
 static int64_t BAWin::*const kInDFields[] = {&BAWin::obs, &BAWin::info};
 static int64_t BAWin::*const kIntFields[] = {&BAWin::cam,     &BAWin::pt,      &BAWin::pt_start, &BAWin::cam_start,
                                              &BAWin::cam_edges, &BAWin::slot,  &BAWin::blk_row,  &BAWin::blk_col,
-                                             &BAWin::blk_diag, &BAWin::blk_mirror, &BAWin::blk_upper, &BAWin::blk_rowid, &BAWin::con_start, &BAWin::con_e1, &BAWin::con_e2, &BAWin::ch_first, &BAWin::ch_last, &BAWin::gbar};
+                                             &BAWin::blk_diag, &BAWin::blk_mirror, &BAWin::blk_upper, &BAWin::blk_rowid, &BAWin::con_start, &BAWin::con_e1, &BAWin::con_e2, &BAWin::ch_first, &BAWin::ch_last,
+                                             &BAWin::ch_desc, &BAWin::cb_blk, &BAWin::cb_start, &BAWin::cb_con, &BAWin::cg_slot, &BAWin::cg_start, &BAWin::cg_edge, &BAWin::gbar};
 static int64_t BAWin::*const kScratchFields[] = {&BAWin::poses_t, &BAWin::pts_t, &BAWin::err, &BAWin::err_t, &BAWin::W,
-                                                 &BAWin::Y,       &BAWin::Hpp,   &BAWin::bp,  &BAWin::Hll,   &BAWin::bl,
+                                                 &BAWin::tv,      &BAWin::Hpp,   &BAWin::bp,  &BAWin::Hll,   &BAWin::bl,
                                                  &BAWin::Dinv,    &BAWin::S,     &BAWin::g,   &BAWin::Minv,  &BAWin::x,
                                                  &BAWin::xl,      &BAWin::A,     &BAWin::Linv, &BAWin::gred,  &BAWin::pcgv};
 #define BA_CHOL_LDS_BYTES (128 * 1024) /* dynamic LDS the blocked Cholesky may take beside the static 25 KB */
 
-/* lay one problem out in the host staging vectors; returns error code */
+/* Lay one problem out in the host staging vectors; returns an error code.  `team`: the window will be spread over
+ * several workgroups (or is too irregular for point chunks) -> per-block contribution lists; otherwise point
+ * chunks for the LDS-staged Schur pass of the batch path. */
 static int stage_problem(const BAProblem *p, std::vector<double> &hO, std::vector<double> &hD, size_t &scratchD,
-                         std::vector<int32_t> &hI, std::vector<uint8_t> &hB, HostWin &hw) {
+                         std::vector<int32_t> &hI, std::vector<uint8_t> &hB, HostWin &hw, bool team) {
     if (!p || p->n_cams <= 0 || p->n_points < 0 || p->n_obs < 0 || !p->poses || !p->fixed ||
         (p->n_points && !p->points) || (p->n_obs && (!p->obs || !p->cam_idx || !p->pt_idx || !p->inv_sigma2)) ||
         p->n_rounds < 1 || p->n_rounds > 4)
@@ -1326,16 +1590,8 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hO, std::vecto
     w.fx = p->fx; w.fy = p->fy; w.cx = p->cx; w.cy = p->cy;
     w.delta = p->huber_delta;
     w.chi2_thr = p->chi2_threshold;
-    /* edges sorted by point (stable) */
-    std::vector<int> cnt(Np + 1, 0);
-    for (int e = 0; e < E; e++) {
+    for (int e = 0; e < E; e++)
         if (p->pt_idx[e] < 0 || p->pt_idx[e] >= Np || p->cam_idx[e] < 0 || p->cam_idx[e] >= Nc) return ORB_E_INVALID;
-        cnt[p->pt_idx[e] + 1]++;
-    }
-    for (int i = 0; i < Np; i++) cnt[i + 1] += cnt[i];
-    std::vector<int> pos(cnt.begin(), cnt.end() - 1);
-    hw.perm.assign(E, 0);
-    for (int e = 0; e < E; e++) hw.perm[pos[p->pt_idx[e]]++] = e;
     /* free camera slots */
     std::vector<int> slot(Nc, -1), slot2cam;
     for (int c = 0; c < Nc; c++)
@@ -1345,6 +1601,30 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hO, std::vecto
         }
     const int Ncf = (int)slot2cam.size();
     w.Ncf = Ncf;
+    /* device order of the points: by the first free camera that sees them (then by id).  Consecutive points then
+       contribute to a compact band of the reduced camera system -- local windows are chain-like, a point is seen by
+       neighbouring keyframes -- which is what lets a chunk of points work on a handful of blocks from LDS. */
+    std::vector<int> first_slot(Np, Ncf);
+    for (int e = 0; e < E; e++) {
+        const int s_ = slot[p->cam_idx[e]];
+        if (s_ >= 0 && s_ < first_slot[p->pt_idx[e]]) first_slot[p->pt_idx[e]] = s_;
+    }
+    std::vector<int> order(Np), &rank = hw.rank;
+    {
+        std::vector<int> head(Ncf + 2, 0); /* counting sort: stable, O(Np) */
+        for (int i = 0; i < Np; i++) head[first_slot[i] + 1]++;
+        for (int i = 0; i <= Ncf; i++) head[i + 1] += head[i];
+        for (int i = 0; i < Np; i++) order[head[first_slot[i]]++] = i;
+    }
+    rank.assign(Np, 0);
+    for (int r = 0; r < Np; r++) rank[order[r]] = r;
+    /* edges sorted by point position (stable) */
+    std::vector<int> cnt(Np + 1, 0);
+    for (int e = 0; e < E; e++) cnt[rank[p->pt_idx[e]] + 1]++;
+    for (int i = 0; i < Np; i++) cnt[i + 1] += cnt[i];
+    std::vector<int> pos(cnt.begin(), cnt.end() - 1);
+    hw.perm.assign(E, 0);
+    for (int e = 0; e < E; e++) hw.perm[pos[rank[p->pt_idx[e]]]++] = e;
     /* camera edge lists (sorted-edge indices) */
     std::vector<int> cstart(Nc + 1, 0), cedges(E);
     for (int k = 0; k < E; k++) cstart[p->cam_idx[hw.perm[k]] + 1]++;
@@ -1353,13 +1633,15 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hO, std::vecto
         std::vector<int> cp(cstart.begin(), cstart.end() - 1);
         for (int k = 0; k < E; k++) cedges[cp[p->cam_idx[hw.perm[k]]]++] = k;
     }
-    /* reduced-system block structure + contribution lists.  A dense Ncf x Ncf table maps a camera-slot pair to its
-       block id (counts first, ids after a row-major sweep), so the O(sum k^2) passes over the co-observation pairs
-       are plain table look-ups: no per-row vectors, no sorting, no binary searches. */
+    /* reduced-system block structure.  A dense Ncf x Ncf table maps a camera-slot pair to its block id (counts
+       first, ids after a row-major sweep), so the O(sum k^2) passes over the co-observation pairs are plain table
+       look-ups: no per-row vectors, no sorting, no binary searches. */
     std::vector<int> eslot(E); /* camera slot of every (sorted) edge, -1 = fixed camera */
     for (int k = 0; k < E; k++) eslot[k] = slot[p->cam_idx[hw.perm[k]]];
     std::vector<int> blk((size_t)Ncf * Ncf, 0); /* pass 1: contributions per pair; pass 2: block id */
-    for (int pt = 0; pt < Np; pt++)
+    int max_deg = 0;
+    for (int pt = 0; pt < Np; pt++) {
+        max_deg = std::max(max_deg, cnt[pt + 1] - cnt[pt]);
         for (int a = cnt[pt]; a < cnt[pt + 1]; a++) {
             const int s1 = eslot[a];
             if (s1 < 0) continue;
@@ -1369,6 +1651,7 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hO, std::vecto
                 if (s2 >= 0) row[s2]++;
             }
         }
+    }
     std::vector<int> brow(Ncf + 1, 0), bcol, bdiag(Ncf, 0), ccount(1, 0);
     for (int s1 = 0; s1 < Ncf; s1++) {
         int *row = &blk[(size_t)s1 * Ncf];
@@ -1378,7 +1661,7 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hO, std::vecto
                 if (s2 == s1) bdiag[s1] = (int)bcol.size();
                 row[s2] = (int)bcol.size();
                 bcol.push_back(s2);
-                ccount.push_back(ccount.back() + (s2 >= s1 ? nc : 0)); /* lower blocks are mirrored, not accumulated */
+                ccount.push_back(ccount.back() + (s2 >= s1 ? nc : 0)); /* only blocks on or above the diagonal are accumulated */
             } else
                 row[s2] = -1;
         }
@@ -1390,8 +1673,12 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hO, std::vecto
     for (int s1 = 0; s1 < Ncf; s1++)
         for (int bk = brow[s1]; bk < brow[s1 + 1]; bk++) bmirror[bk] = blk[(size_t)bcol[bk] * Ncf + s1];
     const int ncon = ccount[nnzb];
-    std::vector<int> ce1(ncon), ce2(ncon);
-    {
+    const bool chunked = !team && max_deg <= BA_CHUNK_E && Ncf > 0;
+    /* ---- list path: per block, the edge pairs (a, b) of the points both cameras see ---- */
+    std::vector<int> ce1, ce2;
+    if (!chunked) {
+        ce1.resize(ncon);
+        ce2.resize(ncon);
         std::vector<int> cp(ccount.begin(), ccount.end() - 1);
         for (int pt = 0; pt < Np; pt++)
             for (int a = cnt[pt]; a < cnt[pt + 1]; a++) {
@@ -1406,6 +1693,106 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hO, std::vecto
                     ce2[k] = b;
                 }
             }
+    }
+    /* ---- batch path: point chunks ---- */
+    std::vector<int> chd, cbb, cbs(1, 0), cbc, cgs, cgst(1, 0), cge;
+    if (chunked) {
+        cbc.reserve(ncon);
+        cge.reserve(E);
+        std::vector<int> seen_blk(nnzb, -1), seen_slot(Ncf, -1); /* chunk id that last touched it -> index in the chunk's list */
+        std::vector<int> blk_pos(nnzb, 0), slot_pos(Ncf, 0);
+        std::vector<int> cb_cnt, cg_cnt, tmp_blk, tmp_slot;
+        bool chunk_overflow = false;
+        int p0 = 0;
+        while (p0 < Np) {
+            int p1 = p0;
+            {
+                /* as many consecutive points as the LDS tiles hold: edges, points, contributions (k (k + 1) / 2 per point
+                   at most), and a bound on the blocks touched (every pair of a point's free cameras at most) */
+                long ncon_c = 0;
+                while (p1 < Np && p1 - p0 < BA_CHUNK_P && cnt[p1 + 1] - cnt[p0] <= BA_CHUNK_E) {
+                    const long k = cnt[p1 + 1] - cnt[p1];
+                    if (p1 > p0 && (ncon_c + k * (k + 1) / 2 > BA_CHUNK_C)) break;
+                    ncon_c += k * (k + 1) / 2;
+                    p1++;
+                }
+            }
+            /* (p1 > p0: a single point never exceeds BA_CHUNK_E edges here; one with more than BA_CHUNK_C contributions
+               or BA_CHUNK_B blocks sends the window to the list path below) */
+            const int e0 = cnt[p0], e1 = cnt[p1], chid = (int)chd.size() / 12;
+            /* pass 1: which blocks / cameras does the chunk touch, and how many contributions each */
+            tmp_blk.clear();
+            tmp_slot.clear();
+            cb_cnt.clear();
+            cg_cnt.clear();
+            for (int pt = p0; pt < p1; pt++)
+                for (int a = cnt[pt]; a < cnt[pt + 1]; a++) {
+                    const int s1 = eslot[a];
+                    if (s1 < 0) continue;
+                    if (seen_slot[s1] != chid) {
+                        seen_slot[s1] = chid;
+                        slot_pos[s1] = (int)tmp_slot.size();
+                        tmp_slot.push_back(s1);
+                        cg_cnt.push_back(0);
+                    }
+                    cg_cnt[slot_pos[s1]]++;
+                    const int *row = &blk[(size_t)s1 * Ncf];
+                    for (int b = cnt[pt]; b < cnt[pt + 1]; b++) {
+                        const int s2 = eslot[b];
+                        if (s2 < s1) continue;
+                        const int bk = row[s2];
+                        if (seen_blk[bk] != chid) {
+                            seen_blk[bk] = chid;
+                            blk_pos[bk] = (int)tmp_blk.size();
+                            tmp_blk.push_back(bk);
+                            cb_cnt.push_back(0);
+                        }
+                        cb_cnt[blk_pos[bk]]++;
+                    }
+                }
+            const int cb0 = (int)cbb.size(), cg0 = (int)cgs.size();
+            if ((int)tmp_blk.size() > BA_CHUNK_B || std::accumulate(cb_cnt.begin(), cb_cnt.end(), 0L) > BA_CHUNK_C) {
+                chunk_overflow = true;
+                break;
+            }
+            /* heaviest blocks first: the 32 sixteen-lane groups of a workgroup take blocks u, u + 32, ... so each round
+               of blocks has similar list lengths (diagonal blocks get a contribution from every edge of their camera) */
+            std::vector<int> ord(tmp_blk.size());
+            for (size_t i = 0; i < ord.size(); i++) ord[i] = (int)i;
+            std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return cb_cnt[x] > cb_cnt[y]; });
+            std::vector<int> cbp(tmp_blk.size()), cgp(tmp_slot.size());
+            for (size_t j = 0; j < ord.size(); j++) {
+                const int i = ord[j];
+                cbb.push_back(tmp_blk[i]);
+                cbp[i] = cbs.back();
+                cbs.push_back(cbs.back() + cb_cnt[i]);
+            }
+            for (size_t i = 0; i < tmp_slot.size(); i++) {
+                cgs.push_back(tmp_slot[i]);
+                cgp[i] = cgst.back();
+                cgst.push_back(cgst.back() + cg_cnt[i]);
+            }
+            cbc.resize(cbs.back());
+            cge.resize(cgst.back());
+            /* pass 2: fill, in point order (the summation order of every block) */
+            for (int pt = p0; pt < p1; pt++)
+                for (int a = cnt[pt]; a < cnt[pt + 1]; a++) {
+                    const int s1 = eslot[a];
+                    if (s1 < 0) continue;
+                    cge[cgp[slot_pos[s1]]++] = a - e0;
+                    const int *row = &blk[(size_t)s1 * Ncf];
+                    for (int b = cnt[pt]; b < cnt[pt + 1]; b++) {
+                        const int s2 = eslot[b];
+                        if (s2 < s1) continue;
+                        cbc[cbp[blk_pos[row[s2]]]++] = (a - e0) | ((b - e0) << 16);
+                    }
+                }
+            const int d[12] = {e0, e1, p0, p1, cb0, (int)cbb.size(), cg0, (int)cgs.size(),
+                               cbs[cb0], cbs.back() - cbs[cb0], cgst[cg0], cgst.back() - cgst[cg0]};
+            chd.insert(chd.end(), d, d + 12);
+            p0 = p1;
+        }
+        if (chunk_overflow) return stage_problem(p, hO, hD, scratchD, hI, hB, hw, true); /* nothing laid out yet */
     }
     /* ---- lay out ---- */
     auto allocO = [&](size_t n) { /* outputs: downloaded */
@@ -1428,6 +1815,11 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hO, std::vecto
         hI.resize(o + n, 0);
         return (int64_t)o;
     };
+    auto putI = [&](const std::vector<int> &v) {
+        const int64_t o = allocI(std::max<size_t>(v.size(), 1));
+        for (size_t i = 0; i < v.size(); i++) hI[o + i] = v[i];
+        return o;
+    };
     w.poses = allocO((size_t)Nc * 7);
     w.poses_t = allocS((size_t)Nc * 7);
     w.pts = allocO((size_t)Np * 3);
@@ -1437,7 +1829,7 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hO, std::vecto
     w.err = allocS((size_t)E * 2);
     w.err_t = allocS((size_t)E * 2);
     w.W = allocS((size_t)E * 18);
-    w.Y = allocS((size_t)E * 18);
+    w.tv = allocS((size_t)Np * 3);
     w.Hpp = allocS((size_t)Ncf * 36);
     w.bp = allocS((size_t)Ncf * 6);
     w.Hll = allocS((size_t)Np * 9);
@@ -1460,7 +1852,8 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hO, std::vecto
         for (int i = 0; i < 4; i++) hO[w.poses + c * 7 + i] = q[i] / nrm;
         for (int i = 0; i < 3; i++) hO[w.poses + c * 7 + 4 + i] = p->poses[c * 7 + 4 + i];
     }
-    for (int i = 0; i < Np * 3; i++) hO[w.pts + i] = p->points[i];
+    for (int i = 0; i < Np; i++)
+        for (int j = 0; j < 3; j++) hO[w.pts + (int64_t)rank[i] * 3 + j] = p->points[i * 3 + j];
     for (int k = 0; k < E; k++) {
         const int e = hw.perm[k];
         hD[w.obs + 2 * k] = p->obs[2 * e];
@@ -1471,26 +1864,19 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hO, std::vecto
     w.pt = allocI(E);
     for (int k = 0; k < E; k++) {
         hI[w.cam + k] = p->cam_idx[hw.perm[k]];
-        hI[w.pt + k] = p->pt_idx[hw.perm[k]];
+        hI[w.pt + k] = rank[p->pt_idx[hw.perm[k]]];
     }
-    w.pt_start = allocI(Np + 1);
-    for (int i = 0; i <= Np; i++) hI[w.pt_start + i] = cnt[i];
-    w.cam_start = allocI(Nc + 1);
-    for (int i = 0; i <= Nc; i++) hI[w.cam_start + i] = cstart[i];
-    w.cam_edges = allocI(E);
-    for (int i = 0; i < E; i++) hI[w.cam_edges + i] = cedges[i];
-    w.slot = allocI(Nc);
-    for (int i = 0; i < Nc; i++) hI[w.slot + i] = slot[i];
+    w.pt_start = putI(cnt);
+    w.cam_start = putI(cstart);
+    w.cam_edges = putI(cedges);
+    w.slot = putI(slot);
     w.blk_row = allocI((size_t)Ncf + 1 + Ncf); /* row starts, then slot -> camera */
     for (int i = 0; i <= Ncf; i++) hI[w.blk_row + i] = brow[i];
     for (int i = 0; i < Ncf; i++) hI[w.blk_row + Ncf + 1 + i] = slot2cam[i];
-    w.blk_col = allocI(nnzb);
-    for (int i = 0; i < nnzb; i++) hI[w.blk_col + i] = bcol[i];
-    w.blk_diag = allocI(Ncf);
-    for (int i = 0; i < Ncf; i++) hI[w.blk_diag + i] = bdiag[i];
-    w.blk_mirror = allocI(nnzb);
-    for (int i = 0; i < nnzb; i++) hI[w.blk_mirror + i] = bmirror[i];
-    w.blk_rowid = allocI(nnzb);
+    w.blk_col = putI(bcol);
+    w.blk_diag = putI(bdiag);
+    w.blk_mirror = putI(bmirror);
+    w.blk_rowid = allocI(std::max(nnzb, 1));
     for (int s1 = 0; s1 < Ncf; s1++)
         for (int bk = brow[s1]; bk < brow[s1 + 1]; bk++) hI[w.blk_rowid + bk] = s1;
     {
@@ -1525,36 +1911,33 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hO, std::vecto
             w.ch_pm = -1; /* marks "no Cholesky" for the kernel and the launch code */
             w.A = w.Linv = 0;
         }
-        w.ch_first = allocI(std::max(nbt, 1));
-        w.ch_last = allocI(std::max(nbt, 1));
-        for (int t = 0; t < nbt; t++) {
-            hI[w.ch_first + t] = first[t];
-            hI[w.ch_last + t] = last[t];
-        }
+        w.ch_first = putI(first);
+        w.ch_last = putI(last);
     }
     {
         std::vector<int> upper;
         for (int i = 0; i < nnzb; i++)
             if (bmirror[i] >= i) upper.push_back(i);
         w.nub = (int)upper.size();
-        w.blk_upper = allocI(upper.size());
-        for (size_t i = 0; i < upper.size(); i++) hI[w.blk_upper + i] = upper[i];
+        w.blk_upper = putI(upper);
     }
-    w.con_start = allocI((size_t)nnzb + 1);
-    for (int i = 0; i <= nnzb; i++) hI[w.con_start + i] = ccount[i];
-    w.con_e1 = allocI(ncon);
-    w.con_e2 = allocI(ncon);
-    for (int i = 0; i < ncon; i++) {
-        hI[w.con_e1 + i] = ce1[i];
-        hI[w.con_e2 + i] = ce2[i];
-    }
+    w.con_start = putI(ccount);
+    w.con_e1 = putI(ce1);
+    w.con_e2 = putI(ce2);
+    w.nchunks = (int)chd.size() / 12;
+    w.ch_desc = putI(chd);
+    w.cb_blk = putI(cbb);
+    w.cb_start = putI(cbs);
+    w.cb_con = putI(cbc);
+    w.cg_slot = putI(cgs);
+    w.cg_start = putI(cgst);
+    w.cg_edge = putI(cge);
     w.gbar = allocI(4); /* two alternating arrival counters + the abort word */
     w.flags = (int64_t)hB.size();
     hB.resize(hB.size() + ((E + 15) & ~15), 0);
     for (int k = 0; k < E; k++) hB[w.flags + k] = (uint8_t)(1 | (p->huber_delta > 0 ? 2 : 0));
     return ORB_OK;
 }
-
 
 /* One batch in flight: its own pinned staging and device buffers, so that the host side of batch k+1 (index sorting,
  * contribution lists, concatenation, upload) and the download / unpacking of batch k-1 overlap the kernels of
@@ -1722,6 +2105,20 @@ template <class F> static void ba_parallel(int nthr, F &&f) {
     for (auto &th : pool) th.join();
 }
 
+/* workgroups per window: as many as fit co-resident AND as the window's size can feed (a team member needs a few
+ * hundred edges per phase to be worth its barrier) */
+static int ba_choose_team(BASolver *s, int nwin, int maxE) {
+    /* k_ba_iteration holds 256 VGPRs per lane: two waves per SIMD = exactly ONE 512-thread workgroup per CU, whatever
+       the LDS would allow.  Not asked of hipOccupancyMaxActiveBlocksPerMultiprocessor: that API can answer one block
+       per CU too high (MI355X_MICROARCH.md, correctness boundaries) and a team barrier would then wait for a workgroup
+       that is not resident. */
+    const int resident = s->cu_count;
+    int want = s->force_team > 0 ? s->force_team : std::max(1, maxE / 768);
+    int G = 1;
+    while (G * 2 <= BA_GMAX && G * 2 <= want && (long)nwin * (G * 2) <= resident) G *= 2;
+    return G;
+}
+
 /* host side of a batch: per-window staging on a pool of host threads (index sorting and the contribution lists are
  * O(sum k^2) per window), then concatenation into the job's pinned buffers */
 static int ba_stage(BASolver *s, BAJob &J, const BAProblem *probs, BAResult *res, int nwin) {
@@ -1740,6 +2137,10 @@ static int ba_stage(BASolver *s, BAJob &J, const BAProblem *probs, BAResult *res
     J.nwin = nwin;
     J.hw.resize(nwin);
     J.wins.resize(nwin);
+    int maxE = 0;
+    for (int i = 0; i < nwin; i++) maxE = std::max(maxE, probs[i].n_obs);
+    J.team = ba_choose_team(s, nwin, maxE);
+    const bool team = J.team > 1;
     if ((int)s->pieces.size() < nwin) s->pieces.resize(nwin);
     std::vector<BAPiece> &pieces = s->pieces;
     const int nthr = std::max(1, std::min<int>(nwin, std::min<int>(16, (int)std::thread::hardware_concurrency())));
@@ -1751,7 +2152,7 @@ static int ba_stage(BASolver *s, BAJob &J, const BAProblem *probs, BAResult *res
             pc.I.clear();
             pc.B.clear();
             pc.scratch = 0;
-            pc.rc = stage_problem(&probs[i], pc.O, pc.D, pc.scratch, pc.I, pc.B, J.hw[i]);
+            pc.rc = stage_problem(&probs[i], pc.O, pc.D, pc.scratch, pc.I, pc.B, J.hw[i], team);
         }
     });
     size_t nO = 0, nD = 0, nI = 0, nB = 0;
@@ -1800,23 +2201,6 @@ static int ba_stage(BASolver *s, BAJob &J, const BAProblem *probs, BAResult *res
     return ORB_OK;
 }
 
-/* workgroups per window: as many as fit co-resident AND as the window's size can feed (a team member needs a few
- * hundred edges per phase to be worth its barrier) */
-static int ba_choose_team(BASolver *s, const BAJob &J, size_t dyn_bytes) {
-    /* k_ba_iteration holds 256 VGPRs per lane: two waves per SIMD = exactly ONE 512-thread workgroup per CU, whatever
-       the LDS would allow.  Not asked of hipOccupancyMaxActiveBlocksPerMultiprocessor: that API can answer one block
-       per CU too high (MI355X_MICROARCH.md, correctness boundaries) and a team barrier would then wait for a workgroup
-       that is not resident. */
-    (void)dyn_bytes;
-    const int resident = s->cu_count;
-    int maxE = 0;
-    for (int i = 0; i < J.nwin; i++) maxE = std::max(maxE, J.wins[i].E);
-    int want = s->force_team > 0 ? s->force_team : std::max(1, maxE / 768);
-    int G = 1;
-    while (G * 2 <= BA_GMAX && G * 2 <= want && (long)J.nwin * (G * 2) <= resident) G *= 2;
-    return G;
-}
-
 /* device side of a batch: upload on the copy-in stream, LM iterations on the compute stream, download of the output
  * region on the copy-out stream; returns without waiting unless a stop flag has to be polled between iterations */
 static int ba_enqueue(BASolver *s, BAJob &J) {
@@ -1856,11 +2240,14 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
             const size_t npw = ((size_t)J.wins[i].Ncf * 6 + 15) & ~(size_t)15;
             dyn_doubles = std::max(dyn_doubles, (int)((size_t)J.wins[i].ch_pm * 17 + 2 * 16 * 17 + npw));
         }
+    }
+    for (int i = 0; i < nwin; i++) /* the LDS tiles of the chunked Schur pass share the region with the Cholesky panel */
+        if (J.team == 1 && J.wins[i].nchunks > 0) dyn_doubles = std::max(dyn_doubles, (int)BA_CHUNK_DOUBLES);
+    {
         static PerDeviceLdsLimit lim;
         BCHK(lim.ensure((const void *)k_ba_iteration, (size_t)dyn_doubles * 8));
     }
-    const int G = ba_choose_team(s, J, (size_t)dyn_doubles * 8);
-    J.team = G;
+    const int G = J.team;
     const int debug = getenv("ORBSLAM_AMD_BA_DEBUG") ? 2 : (prof ? 1 : 0);
     int total_its = 0;
     for (int r = 0; r < P0.n_rounds; r++) total_its += P0.rounds[r];
@@ -1935,7 +2322,8 @@ static int ba_finish(BASolver *s, BAJob &J) {
         for (int i = t; i < nwin; i += nt) {
             const BAWin &w = J.wins[i];
             memcpy(res[i].poses, &J.pD[w.poses], (size_t)w.Nc * 7 * 8);
-            if (w.Np) memcpy(res[i].points, &J.pD[w.pts], (size_t)w.Np * 3 * 8);
+            const int *rank = J.hw[i].rank.data(); /* the device holds the points sorted by first camera */
+            for (int pt = 0; pt < w.Np; pt++) memcpy(res[i].points + (size_t)pt * 3, &J.pD[w.pts + (int64_t)rank[pt] * 3], 24);
             if (res[i].outlier)
                 for (int k = 0; k < w.E; k++) res[i].outlier[J.hw[i].perm[k]] = (J.pB[w.flags + k] & 1) ? 0 : 1;
             res[i].chi2_initial = J.pD[w.st + ST_CHI0];
@@ -1969,7 +2357,13 @@ static int ba_finish(BASolver *s, BAJob &J) {
                                         "backsub+update", "trial chi2+decision"};
         fprintf(stderr, "[ba] window 0 phase ms:");
         for (int k = 0; k < 10; k++) fprintf(stderr, " %s %.2f |", names[k], J.pD[J.wins[0].st + ST_T0 + k] * 1e-5);
-        fprintf(stderr, "\n");
+        fprintf(stderr, "\n[ba] window 0 chunked Schur ms: commit %.2f | fetch issue %.2f | block products %.2f | g + barrier %.2f (chunks %d)\n",
+                J.pD[J.wins[0].st + ST_T0 + 10] * 1e-5, J.pD[J.wins[0].st + ST_T0 + 11] * 1e-5, J.pD[J.wins[0].st + ST_T0 + 12] * 1e-5,
+                J.pD[J.wins[0].st + ST_T0 + 13] * 1e-5, J.wins[0].nchunks);
+        fprintf(stderr, "[ba] window 0 Cholesky ms: assemble %.2f | load diag %.2f | factor diag %.2f | panel %.2f | trailing %.2f | forward %.2f | backward %.2f\n",
+                J.pD[J.wins[0].st + ST_T0 + 16] * 1e-5, J.pD[J.wins[0].st + ST_T0 + 17] * 1e-5, J.pD[J.wins[0].st + ST_T0 + 18] * 1e-5,
+                J.pD[J.wins[0].st + ST_T0 + 19] * 1e-5, J.pD[J.wins[0].st + ST_T0 + 20] * 1e-5, J.pD[J.wins[0].st + ST_T0 + 21] * 1e-5,
+                J.pD[J.wins[0].st + ST_T0 + 22] * 1e-5);
     }
     return ORB_OK;
 }

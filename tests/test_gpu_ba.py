@@ -320,8 +320,8 @@ def test_ba_team_sizes_agree(oracle, nc, npt, monkeypatch):
         _check_estimates(outs[g], ref)
     for g in (4, 64):
         assert np.array_equal(outs[g]["outlier"], outs[1]["outlier"])
-        assert _rel(outs[g]["points"], outs[1]["points"]) < 1e-8
-        assert _rel(outs[g]["poses"], outs[1]["poses"]) < 1e-8
+        assert _rel(outs[g]["points"], outs[1]["points"]) < 1e-6   # another summation order (point chunks vs block lists)
+        assert _rel(outs[g]["poses"], outs[1]["poses"]) < 1e-6
 
 
 def test_ba_submit_wait_pipeline(opt, oracle):
