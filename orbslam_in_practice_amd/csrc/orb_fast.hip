@@ -335,7 +335,7 @@ __device__ __forceinline__ uint32_t fast_score_pair_ld(const uint8_t *ca, int sa
  *           into the queue entry;
  *   pass C  ordered emission of the queue entries selected by the per-cell threshold fallback. */
 __global__ __launch_bounds__(64) void k_fast_cells_wave(OrbGeom g, const uint8_t *pyr, const CellDesc *cells, uint32_t *slab,
-                                                        int32_t *cell_cnt, int ld, int lh) {
+                                                        int32_t *cell_cnt, int ld, int lh, int stop_after) {
     extern __shared__ __attribute__((aligned(16))) uint8_t fw_smem[];
     uint8_t *s_px = fw_smem;                             /* [lh][ld], column 0 <-> x = iniX & ~3 */
     uint8_t *s_sc = fw_smem + ld * lh;                   /* scores, same layout */
@@ -355,12 +355,24 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(OrbGeom g, const uint8_t
     }
     for (int i = lane; i < (ld * lh) >> 2; i += 64) ((uint32_t *)s_sc)[i] = 0u;
     __syncthreads();
+    if (stop_after == 9) return; /* staging only */
     const int iw = rw - 6, ih = rh - 6;
     const int n_in = (iw > 0 && ih > 0) ? iw * ih : 0;
     const float inv_iw = 1.0f / (float)(iw > 0 ? iw : 1);
     const int nch = (n_in + 63) >> 6;
     const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const uint32_t tt = (uint32_t)g.min_th * 0x00010001u;
+    /* The reference runs cv::FAST at iniThFAST and only a cell WITHOUT a single keypoint is redone at minThFAST
+       (src/ORBextractor.cpp:765-773).  Same here: the passes run at iniThFAST first -- non-maximum suppression among
+       the corners of that threshold is exactly cv::FAST(iniThFAST, true), scores below the threshold count as 0 there
+       too -- and the (rare, flat) cell that keeps nothing repeats them at minThFAST.  At minThFAST = 7 more than a
+       third of the pixels of a textured frame are "corners" (every pixel beside an edge has nine contiguous brighter
+       ring pixels); at iniThFAST = 20 a few percent are, so the common case tests and scores a fraction of the
+       pixels. */
+    int nq = 0;
+    bool any_kept = false;
+#pragma unroll 1
+    for (int attempt = 0; attempt < 2 && !any_kept; attempt++) {
+    const uint32_t tt = (uint32_t)(attempt == 0 ? g.ini_th : g.min_th) * 0x00010001u;
     /* pass A0: compass pre-test of every pixel.  A run of 9 on the 16-ring always contains two ADJACENT compass
        points (ring positions 0, 4, 8, 12), and "two adjacent of a 4-cycle" is (N|S)&(E|W): with the sign-bit words
        X[k] of fast_is_corner_ld this is two logic ops for both polarities at once.  About a quarter of the pixels
@@ -387,9 +399,10 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(OrbGeom g, const uint8_t
         nq0 += __popcll(m);
     }
     __syncthreads();
+    if (stop_after == 1) return; /* diagnostics (ORBSLAM_AMD_FAST_STOP): time split of the passes, results invalid */
     /* pass A: the full corner test on the queued pixels, the queue compacted in place (a wave reads its 64
        entries before it writes at most as many at or below them) */
-    int nq = 0;
+    nq = 0;
 #pragma unroll 1
     for (int j0 = 0; j0 < nq0; j0 += 64) {
         const int j = j0 + lane;
@@ -405,6 +418,7 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(OrbGeom g, const uint8_t
         nq += __popcll(m);
     }
     __syncthreads();
+    if (stop_after == 2) return;
     /* pass S: two queued corners per lane (entries j and j + 64 of each 128-entry step) */
 #pragma unroll 1
     for (int j0 = 0; j0 < nq; j0 += 128) {
@@ -420,27 +434,27 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(OrbGeom g, const uint8_t
         }
     }
     __syncthreads();
-    /* pass B */
-    bool any_ini = false;
+    if (stop_after == 3) return;
+    /* pass B: 3x3 non-maximum suppression among the corners of this attempt's threshold (bit 14 = kept) */
 #pragma unroll 1
     for (int j0 = 0; j0 < nq; j0 += 64) {
         const int j = j0 + lane;
-        bool ki = false;
+        bool k = false;
         if (j < nq) {
             const int e = s_q[j];
             const uint8_t *q = s_sc + __mul24((e >> 7) & 127, ld) + (e & 127);
             const int sv = q[0];
-            const bool k = sv > q[-ld - 1] && sv > q[-ld] && sv > q[-ld + 1] && sv > q[-1] && sv > q[1] && sv > q[ld - 1] &&
-                           sv > q[ld] && sv > q[ld + 1];
-            ki = k && sv >= g.ini_th;
-            s_q[j] = (uint16_t)(e | (k ? 1 << 14 : 0) | (ki ? 1 << 15 : 0));
+            k = sv > q[-ld - 1] && sv > q[-ld] && sv > q[-ld + 1] && sv > q[-1] && sv > q[1] && sv > q[ld - 1] &&
+                sv > q[ld] && sv > q[ld + 1];
+            s_q[j] = (uint16_t)(e | (k ? 1 << 14 : 0));
         }
-        any_ini = any_ini || (__ballot(ki) != 0);
+        any_kept = any_kept || (__ballot(k) != 0);
     }
     __syncthreads();
+    } /* attempt: iniThFAST, then minThFAST for a cell that kept nothing (:765-773) */
     /* pass C */
     uint32_t *out = slab + (int64_t)frame * g.slab_frame_count + cd.slab_off;
-    const int want = any_ini ? 1 << 15 : 1 << 14; /* per-cell threshold fallback (:765-773) */
+    const int want = 1 << 14;
     int base = 0;
 #pragma unroll 1
     for (int j0 = 0; j0 < nq; j0 += 64) {
@@ -462,8 +476,9 @@ hipError_t launch_fast(const OrbGeom &g, const OrbBuffers &b, int n_frames, hipS
     dim3 grid(g.total_cells, n_frames);
     if (g.cell_max_rw > 0) { /* one wavefront per cell */
         const int ld = (g.cell_max_rw + 3 + 3) & ~3, lh = g.cell_max_rh;
+        static const int stop_after = getenv("ORBSLAM_AMD_FAST_STOP") ? atoi(getenv("ORBSLAM_AMD_FAST_STOP")) : 0;
         hipLaunchKernelGGL(k_fast_cells_wave, grid, dim3(64), (size_t)2 * ld * lh + 2 * (size_t)(g.cell_max_rw * g.cell_max_rh), st, g, (const uint8_t *)b.pyr, b.cells, b.slab,
-                           b.cell_cnt, ld, lh);
+                           b.cell_cnt, ld, lh, stop_after);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, st, g, (const uint8_t *)b.pyr, b.cells, b.slab, b.cell_cnt);
