@@ -215,11 +215,19 @@ __global__ __launch_bounds__(256) void k_match_knn(MatchArgs A) {
                 bool cand = true;
                 if (!brute) cand = fabsf(s_x[j] - px) < r && fabsf(s_y[j] - py) < r;
                 const int d = hamming256(a, s_d[2 * j], s_d[2 * j + 1]);
+                /* A candidate farther than TH_LOW can only ever act as the SECOND best, and it changes the ratio test
+                   (:65-67: best <= TH_LOW && best < second * ratio) only if TH_LOW >= d * ratio.  Beyond that it cannot
+                   influence any decision of phase 2 -- with it or without it the query is accepted, or has no candidate
+                   within TH_LOW -- so it is not kept: the list then ends in KNONE, which phase 2 reads as "no further
+                   candidate that matters".  Random descriptors sit ~128 bits apart: nearly every step of the scan skips
+                   the sorted insert wave-wide (a third of this loop's instructions). */
+                cand = cand && !(d > TH_LOW && (float)TH_LOW < (float)d * A.nnratio);
+                if (!cand) continue;
                 key_t key;
                 if (KEY32)
-                    key = cand ? (((uint32_t)d << (brute ? 16 : 23)) | ord) : KNONE;
+                    key = ((uint32_t)d << (brute ? 16 : 23)) | ord;
                 else
-                    key = cand ? (key_t)(((uint64_t)(uint32_t)d << 32) | ord) : KNONE;
+                    key = (key_t)(((uint64_t)(uint32_t)d << 32) | ord);
                 if (KEY32) {
                     /* branch-free sorted insert: with a[k-1] <= a[k], the new a[k] is median(a[k-1], key, a[k])
                        (one v_med3_u32 each) -- a no-op for key = KNONE */
