@@ -371,10 +371,6 @@ def main():
     if rank == 0:
         fps = world * B * S * args.steps / elapsed
         ab = algorithmic_bytes_per_frame(ext.level_sizes(W, H), n_kp)
-        # the dominant KERNEL: the single-launch stage with the longest average duration
-        # ("pyramid" is several launches -- level-0 copy + resizes -- and is listed under roofline_stages only)
-        timed = {k: v for k, v in stage_ms.items() if ab.get(k, 0) > 0 and k in SINGLE_KERNEL_STAGES}
-        dom = max(timed, key=timed.get)
         tj = {}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -382,6 +378,15 @@ def main():
                 tj = json.load(open(tpath))
             except Exception:
                 tj = {}
+        # The dominant KERNEL.  The two launch lanes keep the GPU's vector ALUs ~95 % busy (profiles/r02_pmc_sq_*.json), so
+        # the kernel that bounds the pipeline is the one that issues the most VALU instructions per batch (PMC
+        # SQ_INSTS_VALU, profiles/traffic.json), not the one whose in-flight HIP-event interval happens to be longest
+        # -- the latency-bound single-wave stages (quadtree, match resolution) stretch to ~0.8 ms beside the others
+        # while occupying a few percent of the machine.  Without the PMC file: the longest single-launch stage.
+        # ("pyramid" is several launches -- level-0 copy + resizes -- and is listed under roofline_stages only)
+        timed = {k: v for k, v in stage_ms.items() if ab.get(k, 0) > 0 and k in SINGLE_KERNEL_STAGES}
+        by_valu = {k: tj["valu_insts_" + k] for k in timed if "valu_insts_" + k in tj}
+        dom = max(by_valu, key=by_valu.get) if by_valu else max(timed, key=timed.get)
 
         def stage_roofline(k):
             # one launch covers Bh frames; PMC traffic was collected per launch at tj['_batch'] frames and the

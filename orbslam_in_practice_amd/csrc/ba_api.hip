@@ -2273,11 +2273,18 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
             int first = it == 0 ? 1 : 0, solver = s->solver, g = G, sq = seq++, nit = std::min(per_launch, P0.rounds[round] - it);
             double tol2 = s->pcg_tol2;
             int dbg = debug;
-            if (G > 1) {
-                /* a team needs all its workgroups resident at once: cooperative launch */
+            static const bool no_coop = getenv("ORBSLAM_AMD_BA_NO_COOP") != nullptr; /* diagnostics: rocprofv3 (ROCm 7.2) crashes
+                                                                                          at process exit after a cooperative launch */
+            if (G > 1 && !no_coop) {
+                /* a team needs all its workgroups resident at once: cooperative launch (the runtime checks the grid
+                   against the device and never runs two cooperative kernels side by side) */
                 void *args[] = {&bufs, &first, &tol2, &pcg_maxit, &dbg, &solver, &dyn_doubles, &g, &sq, &nit};
                 BCHK(hipLaunchCooperativeKernel((const void *)k_ba_iteration, dim3(nwin * G), dim3(BA_T), args,
                                                 (size_t)dyn_doubles * 8, s->stream));
+            } else if (G > 1) {
+                hipLaunchKernelGGL(k_ba_iteration, dim3(nwin * G), dim3(BA_T), (size_t)dyn_doubles * 8, s->stream, bufs, first, tol2,
+                                   pcg_maxit, dbg, solver, dyn_doubles, g, sq, nit);
+                BCHK(hipGetLastError());
             } else {
                 hipLaunchKernelGGL(k_ba_iteration, dim3(nwin), dim3(BA_T), (size_t)dyn_doubles * 8, s->stream, bufs, first, tol2,
                                    pcg_maxit, dbg, solver, dyn_doubles, 1, sq, nit);

@@ -472,7 +472,8 @@ template <int NN> static hipError_t launch_qt(const OrbGeom &g, const OrbBuffers
        in global memory -- 2048 workgroups holding 100 KB of LDS each would starve the kernels running beside them) */
     const size_t fixed = (sizeof(QtShared<NN>) + 15) & ~(size_t)15;
     const size_t room = fixed < 128 * 1024 ? 128 * 1024 - fixed : 0; /* keep the workgroup under 128 KB of LDS */
-    const int lds_keys = n_frames <= 8 ? (int)std::min<size_t>(12288, room / 8) : 0;
+    static const int batch_keys = getenv("ORBSLAM_AMD_QT_LDS_KEYS") ? atoi(getenv("ORBSLAM_AMD_QT_LDS_KEYS")) : 0;
+    const int lds_keys = n_frames <= 8 ? (int)std::min<size_t>(12288, room / 8) : (int)std::min<size_t>(batch_keys, room / 8);
     const size_t lds = ((sizeof(QtShared<NN>) + 15) & ~(size_t)15) + (size_t)lds_keys * 8;
     static PerDeviceLdsLimit lim2;
     {
