@@ -158,6 +158,29 @@ int orb_features_in_area(OrbMatcher *m, const OrbFrameView *f, const float *quer
                          int n_queries, int32_t *out_idx, int cap, int32_t *out_count);
 
 
+/* ---- ORBmatcher::SearchByProjection / SearchByBoW --------------------------------------------------------
+ * Both have EMPTY bodies in the reference (include/ORBmatcher.h:22,24) although Tracking calls them
+ * (src/Tracking.cpp:298,344,348): there is no reference behaviour to be identical to.  These entry points implement
+ * upstream ORB-SLAM2's monocular semantics on the reference's data model (oracle/match_oracle.cpp states them line
+ * by line): PARITY UNPINNED by construction.  The candidate scan (projection, window / level filter, Hamming
+ * distances, the closest candidates per feature) runs on the device, the sequential walk over the features (a
+ * feature taken by an earlier one is closed to later ones) and the rotation histogram on the host.  Host pointers.
+ *
+ * orb_search_by_projection: last_flags[n_last]: bit0 = the feature holds a map point and is not an outlier, bit1 = that
+ * map point has observations; last_xw[n_last*3] world positions (read where bit0 is set); Rcw9 / tcw3 the current
+ * frame's pose (x_c = Rcw x_w + tcw); scale_factors[nlevels]; cur_taken[n_cur] in/out: the feature holds a map point
+ * with observations; cur_match[n_cur] out: index of the last-frame feature whose map point it receives, or -1.
+ * TH_HIGH = 100; rotation histogram as in the reference's SearchForInitialization. */
+int orb_search_by_projection(OrbMatcher *m, const OrbFrameView *cur, const OrbFrameView *last, const uint8_t *last_flags,
+                             const double *last_xw, const double *Rcw9, const double *tcw3, double fx, double fy, double cx,
+                             double cy, const float *scale_factors, int nlevels, uint8_t *cur_taken, float th,
+                             int check_orientation, int32_t *cur_match, int32_t *n_matches);
+/* orb_search_by_bow: the reference has no vocabulary (ComputeBoW is empty), i.e. one node holding every feature: for every
+ * keyframe feature with kf_valid[i] != 0, in index order, best and second best distance over the frame features not
+ * matched yet; accepted if best <= TH_LOW (50) and best < nnratio * second.  f_match[n_f] out: keyframe feature or -1. */
+int orb_search_by_bow(OrbMatcher *m, const OrbFrameView *kf, const uint8_t *kf_valid, const OrbFrameView *f, float nnratio,
+                      int check_orientation, int32_t *f_match, int32_t *n_matches);
+
 /* Batched, device-resident matching of n_pairs frame pairs (pair p: frame a[p] against frame b[p] of
  * the slabs an extractor produced with capacity `cap`): d_kps[n_frames*cap], d_desc[n_frames*cap*32],
  * d_counts[n_frames].  prev_matched is taken to be F1's own keypoint positions (first call of

@@ -104,10 +104,107 @@ template <class FrameT> class ORBmatcherT {
         ind3 = c;
     }
 
-    /* empty-bodied in the reference (include/ORBmatcher.h:22,24 -- `{}` with an int return type, i.e. no defined
-     * result): kept as explicit "no matches".  SURVEY N4: nothing in the reference to be identical to. */
-    template <class KF, class MP> int SearchByBoW(KF *, const FrameT &, std::vector<MP *> &) { return 0; }
-    int SearchByProjection(FrameT &, const FrameT &, const float, const bool) { return 0; }
+    /* per-level scale factors for SearchByProjection's search radius (ORBextractor::GetScaleFactors()); default 1.2^l */
+    static std::vector<float> &ScaleFactors() {
+        static std::vector<float> v = [] {
+            std::vector<float> t(8);
+            float s = 1.f;
+            for (int i = 0; i < 8; i++) {
+                t[i] = s;
+                s *= 1.2f;
+            }
+            return t;
+        }();
+        return v;
+    }
+
+    /* SURVEY N4.  Both functions have EMPTY bodies in the reference (include/ORBmatcher.h:22,24 -- `{}` with an int
+     * return type) although Tracking calls them (src/Tracking.cpp:298,344,348): nothing in the reference to be identical
+     * to.  They implement upstream ORB-SLAM2's monocular semantics on the reference's data model (stated line by line in
+     * oracle/match_oracle.cpp; PARITY UNPINNED by construction) over orb_search_by_projection / orb_search_by_bow.
+     *
+     * SearchByProjection: every map point of the last frame (not an outlier) is projected with the current frame's
+     * pose, the closest free feature inside th * scaleFactor[octave] on the neighbouring pyramid levels takes it if the
+     * Hamming distance is <= 100; rotation-consistency histogram; CurrentFrame.mvpMappts is filled.  Needs of FrameT,
+     * beyond SearchForInitialization's: GetR(), GetT(), static GetCameraPara(cv::Mat&), mvpMappts, mvbOutlier; of the
+     * map point type: Getpos(), Obsnums(). */
+    int SearchByProjection(FrameT &CurrentFrame, const FrameT &LastFrame, const float th, const bool bMono) {
+        (void)bMono; /* the reference is monocular throughout */
+        const std::vector<cv::KeyPoint> kc = CurrentFrame.GetUnKeyPts(), kl = LastFrame.GetUnKeyPts();
+        const cv::Mat dc = CurrentFrame.GetDescriptors(), dl = LastFrame.GetDescriptors();
+        const int nc = (int)kc.size(), nl = (int)kl.size();
+        if (nc == 0 || nl == 0) return 0;
+        ensure(std::max(nc, nl));
+        std::vector<unsigned char> bc((size_t)nc * 32), bl((size_t)nl * 32), flags(nl, 0), taken(nc, 0);
+        for (int i = 0; i < nc; i++) memcpy(&bc[(size_t)i * 32], dc.ptr(i), 32);
+        for (int i = 0; i < nl; i++) memcpy(&bl[(size_t)i * 32], dl.ptr(i), 32);
+        std::vector<double> xw((size_t)nl * 3, 0.0);
+        for (int i = 0; i < nl && i < (int)LastFrame.mvpMappts.size(); i++) {
+            auto *mp = LastFrame.mvpMappts[i];
+            if (!mp || (i < (int)LastFrame.mvbOutlier.size() && LastFrame.mvbOutlier[i])) continue;
+            const auto X = mp->Getpos();
+            for (int k = 0; k < 3; k++) xw[(size_t)i * 3 + k] = X(k);
+            flags[i] = (unsigned char)(1 | (mp->Obsnums() > 0 ? 2 : 0));
+        }
+        if ((int)CurrentFrame.mvpMappts.size() < nc) CurrentFrame.mvpMappts.resize(nc, nullptr);
+        for (int j = 0; j < nc; j++) {
+            auto *mp = CurrentFrame.mvpMappts[j];
+            taken[j] = (mp && mp->Obsnums() > 0) ? 1 : 0;
+        }
+        const auto R = CurrentFrame.GetR();
+        const auto t = CurrentFrame.GetT();
+        double Rcw[9], tcw[3];
+        for (int i = 0; i < 3; i++) {
+            for (int j = 0; j < 3; j++) Rcw[i * 3 + j] = R(i, j);
+            tcw[i] = t(i);
+        }
+        cv::Mat camk;
+        CurrentFrame.GetCameraPara(camk);
+        float b[4];
+        bounds(b);
+        OrbFrameView vc = {(const OrbKeyPoint *)kc.data(), bc.data(), nc, b[0], b[1], b[2], b[3]};
+        OrbFrameView vl = {(const OrbKeyPoint *)kl.data(), bl.data(), nl, b[0], b[1], b[2], b[3]};
+        std::vector<int32_t> match(nc, -1);
+        int32_t n = 0;
+        if (orb_search_by_projection(m_, &vc, &vl, flags.data(), xw.data(), Rcw, tcw, (double)camk.template at<float>(0, 0),
+                                     (double)camk.template at<float>(1, 1), (double)camk.template at<float>(0, 2),
+                                     (double)camk.template at<float>(1, 2), ScaleFactors().data(), (int)ScaleFactors().size(),
+                                     taken.data(), th, mbCheckOrientation ? 1 : 0, match.data(), &n) != ORB_OK)
+            orbslam_amd_fatal("ORBmatcher::SearchByProjection");
+        for (int j = 0; j < nc; j++)
+            if (match[j] >= 0) CurrentFrame.mvpMappts[j] = LastFrame.mvpMappts[match[j]];
+        return n;
+    }
+
+    /* SearchByBoW: the reference has no vocabulary (KeyFrame::ComputeBoW / Frame::ComputeBOW are empty), i.e. a single
+     * node: every keyframe feature with a good map point against every frame feature not matched yet, TH_LOW and the
+     * nearest-neighbour ratio, rotation histogram.  vpMatches12[j] = the map point frame feature j receives.  KF needs
+     * GetMapPoints(), mvUnKeypts, mcvDescriptors; the frame is taken by value as in the reference's signature. */
+    template <class KF, class MP> int SearchByBoW(KF *pKF, FrameT F, std::vector<MP *> &vpMatches12) {
+        const std::vector<cv::KeyPoint> &kk = pKF->mvUnKeypts;
+        const std::vector<cv::KeyPoint> kf = F.GetUnKeyPts();
+        const cv::Mat dk = pKF->mcvDescriptors, df = F.GetDescriptors();
+        const int nk = (int)kk.size(), nf = (int)kf.size();
+        vpMatches12.assign(nf, static_cast<MP *>(nullptr));
+        if (nk == 0 || nf == 0) return 0;
+        ensure(std::max(nk, nf));
+        const std::vector<MP *> mps = pKF->GetMapPoints();
+        std::vector<unsigned char> bk((size_t)nk * 32), bf((size_t)nf * 32), valid(nk, 0);
+        for (int i = 0; i < nk; i++) memcpy(&bk[(size_t)i * 32], dk.ptr(i), 32);
+        for (int i = 0; i < nf; i++) memcpy(&bf[(size_t)i * 32], df.ptr(i), 32);
+        for (int i = 0; i < nk && i < (int)mps.size(); i++) valid[i] = (mps[i] && !mps[i]->IsBad()) ? 1 : 0;
+        float b[4];
+        bounds(b);
+        OrbFrameView vk = {(const OrbKeyPoint *)kk.data(), bk.data(), nk, b[0], b[1], b[2], b[3]};
+        OrbFrameView vf = {(const OrbKeyPoint *)kf.data(), bf.data(), nf, b[0], b[1], b[2], b[3]};
+        std::vector<int32_t> match(nf, -1);
+        int32_t n = 0;
+        if (orb_search_by_bow(m_, &vk, valid.data(), &vf, mfNNratio, mbCheckOrientation ? 1 : 0, match.data(), &n) != ORB_OK)
+            orbslam_amd_fatal("ORBmatcher::SearchByBoW");
+        for (int j = 0; j < nf; j++)
+            if (match[j] >= 0) vpMatches12[j] = mps[match[j]];
+        return n;
+    }
 
   protected:
     static float *explicit_bounds() {

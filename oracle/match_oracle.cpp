@@ -255,4 +255,144 @@ int orc_search_for_initialization(const OrcFrameView *F1, const OrcFrameView *F2
     return nmatches;
 }
 
+
+/* ---- ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) ----
+ * The reference declares it with an EMPTY body (include/ORBmatcher.h:24) and calls it from
+ * Tracking::TrackWithMotionModel (src/Tracking.cpp:344,348): there is nothing in the reference to be identical to, so
+ * this restates upstream ORB-SLAM2's monocular semantics on the reference's data model (PARITY UNPINNED by
+ * construction): every last-frame feature that holds a map point and is not an outlier is projected with the current
+ * pose (x_c = Rcw x_w + tcw; rejected behind the camera or outside the image bounds), candidates =
+ * CurrentFrame.GetFeaturesInArea(u, v, th * scaleFactor[octave], octave - 1, octave + 1) (src/Frame.cpp:219-271) that do
+ * not already hold a map point with observations, best Hamming distance over them (first minimum in candidate order)
+ * accepted if <= TH_HIGH = 100; the accepted feature takes the map point (and, if that point has observations, is
+ * closed to later features); rotation-consistency histogram as in the reference's own SearchForInitialization
+ * (30 bins, factor 30/360, three maxima, src/ORBmatcher.cpp:79-118).  Deviations from upstream, all forced by the
+ * reference's data model: the map point's descriptor is the last frame's descriptor row (MapPoint has no
+ * GetDescriptor), and the histogram factor is the reference's (upstream's 1/HISTO_LENGTH is a known slip).
+ * last_flags[i]: bit0 = holds a map point and is not an outlier, bit1 = that map point has observations.
+ * cur_taken[j] in/out: feature j holds a map point with observations.  cur_match[j] out: index into the last frame. */
+int orc_search_by_projection(const OrcFrameView *cur, const OrcFrameView *last, const uint8_t *last_flags, const double *last_xw,
+                             const double *Rcw, const double *tcw, double fx, double fy, double cx, double cy,
+                             const float *scale_factors, int nlevels, uint8_t *cur_taken, float th, int check_ori,
+                             int32_t *cur_match) {
+    const int TH_HIGH = 100;
+    int nmatches = 0;
+    for (int j = 0; j < cur->n; j++) cur_match[j] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = HISTO_LENGTH / 360.0f;
+    FrameGrid g(cur);
+    for (int i = 0; i < last->n; i++) {
+        if (!(last_flags[i] & 1)) continue;
+        const double *X = last_xw + (size_t)i * 3;
+        const double xc = Rcw[0] * X[0] + Rcw[1] * X[1] + Rcw[2] * X[2] + tcw[0];
+        const double yc = Rcw[3] * X[0] + Rcw[4] * X[1] + Rcw[5] * X[2] + tcw[1];
+        const double zc = Rcw[6] * X[0] + Rcw[7] * X[1] + Rcw[8] * X[2] + tcw[2];
+        const double invzc = 1.0 / zc;
+        if (invzc < 0) continue;
+        const float u = (float)(fx * xc * invzc + cx), v = (float)(fy * yc * invzc + cy);
+        if (u < cur->min_x || u > cur->max_x) continue;
+        if (v < cur->min_y || v > cur->max_y) continue;
+        const int nLastOctave = last->kps[i].octave;
+        if (nLastOctave < 0 || nLastOctave >= nlevels) continue;
+        const float radius = th * scale_factors[nLastOctave];
+        const std::vector<size_t> vIndices2 = g.GetFeaturesInArea(u, v, radius, nLastOctave - 1, nLastOctave + 1);
+        if (vIndices2.empty()) continue;
+        const uint8_t *dMP = last->desc + (size_t)i * 32;
+        int bestDist = 256, bestIdx2 = -1;
+        for (size_t k = 0; k < vIndices2.size(); k++) {
+            const size_t i2 = vIndices2[k];
+            if (cur_taken[i2]) continue;
+            const int dist = DescriptorDistance(dMP, cur->desc + i2 * 32);
+            if (dist < bestDist) {
+                bestDist = dist;
+                bestIdx2 = (int)i2;
+            }
+        }
+        if (bestDist <= TH_HIGH) {
+            cur_match[bestIdx2] = i;
+            if (last_flags[i] & 2) cur_taken[bestIdx2] = 1;
+            nmatches++;
+            if (check_ori) {
+                float rot = last->kps[i].angle - cur->kps[bestIdx2].angle;
+                if (rot < 0.0f) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (check_ori) {
+        int32_t sizes[HISTO_LENGTH];
+        for (int b = 0; b < HISTO_LENGTH; b++) sizes[b] = (int32_t)rotHist[b].size();
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        ComputeThreeMaxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int b = 0; b < HISTO_LENGTH; b++) {
+            if (b == ind1 || b == ind2 || b == ind3) continue;
+            for (size_t k = 0; k < rotHist[b].size(); k++) {
+                cur_match[rotHist[b][k]] = -1; /* upstream: CurrentFrame.mvpMapPoints[..] = NULL -- the feature is free again */
+                cur_taken[rotHist[b][k]] = 0;
+                nmatches--;
+            }
+        }
+    }
+    return nmatches;
+}
+
+/* ---- ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame F, vector<MapPoint*>& vpMatches) ----
+ * Empty body in the reference (include/ORBmatcher.h:22), called from Tracking::TrackReferenceKeyFrame
+ * (src/Tracking.cpp:298).  Upstream walks the two BoW feature vectors and compares only features that fall into the
+ * same vocabulary node; the reference has no vocabulary at all (KeyFrame::ComputeBoW and Frame::ComputeBOW are
+ * empty, src/KeyFrame.cpp:19, src/Frame.cpp:274), i.e. ONE node holding every feature -- which is what this restates
+ * (PARITY UNPINNED by construction): for every keyframe feature with a good map point, in index order, best and second
+ * best distance over the frame features not matched yet, accepted if best <= TH_LOW and best < ratio * second,
+ * rotation histogram as above.  kf_valid[i]: keyframe feature i holds a good map point.  f_match[j] out: keyframe
+ * feature whose map point frame feature j receives, or -1. */
+int orc_search_by_bow(const OrcFrameView *kf, const uint8_t *kf_valid, const OrcFrameView *f, float nnratio, int check_ori,
+                      int32_t *f_match) {
+    int nmatches = 0;
+    for (int j = 0; j < f->n; j++) f_match[j] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = HISTO_LENGTH / 360.0f;
+    for (int i = 0; i < kf->n; i++) {
+        if (!kf_valid[i]) continue;
+        const uint8_t *dKF = kf->desc + (size_t)i * 32;
+        int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+        for (int j = 0; j < f->n; j++) {
+            if (f_match[j] >= 0) continue;
+            const int dist = DescriptorDistance(dKF, f->desc + (size_t)j * 32);
+            if (dist < bestDist1) {
+                bestDist2 = bestDist1;
+                bestDist1 = dist;
+                bestIdxF = j;
+            } else if (dist < bestDist2)
+                bestDist2 = dist;
+        }
+        if (bestDist1 <= TH_LOW && (float)bestDist1 < nnratio * (float)bestDist2) {
+            f_match[bestIdxF] = i;
+            nmatches++;
+            if (check_ori) {
+                float rot = kf->kps[i].angle - f->kps[bestIdxF].angle;
+                if (rot < 0.0f) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdxF);
+            }
+        }
+    }
+    if (check_ori) {
+        int32_t sizes[HISTO_LENGTH];
+        for (int b = 0; b < HISTO_LENGTH; b++) sizes[b] = (int32_t)rotHist[b].size();
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        ComputeThreeMaxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int b = 0; b < HISTO_LENGTH; b++) {
+            if (b == ind1 || b == ind2 || b == ind3) continue;
+            for (size_t k = 0; k < rotHist[b].size(); k++) {
+                f_match[rotHist[b][k]] = -1;
+                nmatches--;
+            }
+        }
+    }
+    return nmatches;
+}
+
 } /* extern "C" */

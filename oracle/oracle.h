@@ -85,6 +85,13 @@ void orc_features_in_area(const OrcFrameView *f, const float *qxyr, const int32_
 int orc_search_for_initialization(const OrcFrameView *f1, const OrcFrameView *f2, float *prev_matched_xy,
                                   int32_t *matches12, int window_size, float nnratio, int check_ori,
                                   int clone_mode);
+/* SURVEY N4 (empty bodies in the reference: upstream semantics restated, parity unpinned by construction) */
+int orc_search_by_projection(const OrcFrameView *cur, const OrcFrameView *last, const uint8_t *last_flags, const double *last_xw,
+                             const double *Rcw, const double *tcw, double fx, double fy, double cx, double cy,
+                             const float *scale_factors, int nlevels, uint8_t *cur_taken, float th, int check_ori,
+                             int32_t *cur_match);
+int orc_search_by_bow(const OrcFrameView *kf, const uint8_t *kf_valid, const OrcFrameView *f, float nnratio, int check_ori,
+                      int32_t *f_match);
 void orc_compute_three_maxima(const int32_t *histo_sizes, int L, int32_t *ind1, int32_t *ind2,
                               int32_t *ind3);
 

@@ -347,3 +347,36 @@ def pose_optimization(pose, xw, obs, inv_sigma2, fx, fy, cx, cy):
     lib().orc_pose_optimization(_p(pose), _p(xw), _p(obs), _p(inv_sigma2), n, fx, fy, cx, cy, _p(outlier),
                                 C.byref(ninl))
     return pose, outlier[:n], ninl.value
+
+
+def search_by_projection(cur_kps, cur_desc, last_kps, last_desc, bounds, last_flags, last_xw, Rcw, tcw, fx, fy, cx, cy,
+                         scale_factors, cur_taken, th, check_ori=True):
+    """SURVEY N4 (upstream semantics, parity unpinned): returns (nmatches, cur_match[n_cur], cur_taken[n_cur])"""
+    L = lib()
+    L.orc_search_by_projection.argtypes = [C.POINTER(FrameView), C.POINTER(FrameView), C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_int,
+                                           C.c_void_p, C.c_float, C.c_int, C.c_void_p]
+    vc, kc = _view(cur_kps, cur_desc, bounds)
+    vl, kl = _view(last_kps, last_desc, bounds)
+    fl = np.ascontiguousarray(last_flags, np.uint8)
+    xw = np.ascontiguousarray(last_xw, np.float64)
+    R = np.ascontiguousarray(Rcw, np.float64).reshape(9)
+    t = np.ascontiguousarray(tcw, np.float64).reshape(3)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    taken = np.ascontiguousarray(cur_taken, np.uint8).copy()
+    m = np.full(max(len(cur_kps), 1), -1, np.int32)
+    n = L.orc_search_by_projection(C.byref(vc), C.byref(vl), _p(fl), _p(xw), _p(R), _p(t), fx, fy, cx, cy, _p(sf), len(sf),
+                                   _p(taken), float(th), 1 if check_ori else 0, _p(m))
+    return n, m[:len(cur_kps)], taken
+
+
+def search_by_bow(kf_kps, kf_desc, kf_valid, f_kps, f_desc, bounds, nnratio=0.7, check_ori=True):
+    """SURVEY N4 (one-node vocabulary, parity unpinned): returns (nmatches, f_match[n_f])"""
+    L = lib()
+    L.orc_search_by_bow.argtypes = [C.POINTER(FrameView), C.c_void_p, C.POINTER(FrameView), C.c_float, C.c_int, C.c_void_p]
+    vk, kk = _view(kf_kps, kf_desc, bounds)
+    vf, kf_ = _view(f_kps, f_desc, bounds)
+    valid = np.ascontiguousarray(kf_valid, np.uint8)
+    m = np.full(max(len(f_kps), 1), -1, np.int32)
+    n = L.orc_search_by_bow(C.byref(vk), _p(valid), C.byref(vf), float(nnratio), 1 if check_ori else 0, _p(m))
+    return n, m[:len(f_kps)]

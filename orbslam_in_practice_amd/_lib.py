@@ -61,7 +61,7 @@ EXPORTS = [
     "orb_set_profiling", "orb_get_stage_ms", "orb_matcher_set_profiling", "orb_matcher_get_ms", "orb_matcher_get_stage_ms", "orb_features_in_area",
     "orb_descriptor_distance", "orb_compute_three_maxima", "orb_matcher_create", "orb_matcher_destroy",
     "orb_matcher_stream", "orb_matcher_synchronize", "orb_hamming_knn2", "orb_match_init",
-    "orb_match_batch_device", "ba_create", "ba_destroy", "ba_solve", "ba_solve_batch", "ba_submit_batch", "ba_wait", "ba_set_profiling", "ba_get_iteration_ms",
+    "orb_match_batch_device", "orb_search_by_projection", "orb_search_by_bow", "ba_create", "ba_destroy", "ba_solve", "ba_solve_batch", "ba_submit_batch", "ba_wait", "ba_set_profiling", "ba_get_iteration_ms",
     "ba_pose_optimization", "ba_pose_optimization_batch",
 ]
 
@@ -122,6 +122,9 @@ def lib():
     L.orb_match_init.argtypes = [vp, C.POINTER(OrbFrameView), C.POINTER(OrbFrameView), vp, vp, i32, f32, i32, vp]
     L.orb_match_batch_device.argtypes = [vp, vp, vp, vp, i32, vp, vp, i32, f32, f32, f32, f32, i32, f32, i32, vp,
                                          vp, vp]
+    L.orb_search_by_projection.argtypes = [vp, C.POINTER(OrbFrameView), C.POINTER(OrbFrameView), vp, vp, vp, vp, C.c_double,
+                                           C.c_double, C.c_double, C.c_double, vp, i32, vp, f32, i32, vp, vp]
+    L.orb_search_by_bow.argtypes = [vp, C.POINTER(OrbFrameView), vp, C.POINTER(OrbFrameView), f32, i32, vp, vp]
     L.ba_create.argtypes = [i32, i32, i32, i32, i32, C.POINTER(vp)]
     L.ba_destroy.argtypes = [vp]
     L.ba_destroy.restype = None

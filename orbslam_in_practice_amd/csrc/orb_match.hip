@@ -30,6 +30,8 @@
 #include <algorithm>
 #include <cstring>
 #include <string>
+#include <utility>
+#include <vector>
 
 #define GRID_COLS 64
 #define GRID_ROWS 48
@@ -589,6 +591,144 @@ __global__ __launch_bounds__(64) void k_features_in_area(const OrbKeyPoint *kps,
     if (lane == 0) out_count[q] = nc;
 }
 
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * SURVEY N4 -- the candidate scan behind ORBmatcher::SearchByProjection / SearchByBoW (empty bodies in the
+ * reference, include/ORBmatcher.h:22,24; upstream ORB-SLAM2 semantics, see oracle/match_oracle.cpp).  One query
+ * per lane: a descriptor, a window (x, y, r; r < 0: every keypoint is a candidate, in index order) and a level
+ * range; the frame's keypoints stream through LDS in 512-keypoint tiles; kept: the QK_TOP smallest
+ * (distance << 32 | grid cell << 16 | index) keys with distance <= keep_max_d -- a farther candidate cannot change
+ * what the sequential walk decides (SearchByProjection accepts on best <= TH_HIGH alone; SearchByBoW's ratio test
+ * needs a second best only while TH_LOW >= d * ratio), so a list that ends early is complete for that purpose.
+ * The walk itself (a feature taken by an earlier query is closed to later ones) runs on the host over these
+ * lists. */
+#define QK_TOP 8
+struct QueryArgs {
+    const OrbKeyPoint *kps2;
+    const uint8_t *desc2;
+    int n2;
+    const uint8_t *qdesc; /* [nq][32] */
+    const float *qxyr;    /* [nq][3] */
+    const int32_t *qlvl;  /* [nq][2] (minLevel, maxLevel) or NULL */
+    int nq;
+    float min_x, max_x, min_y, max_y;
+    int keep_max_d;
+    unsigned long long *out; /* [nq][QK_TOP], ~0 = none */
+};
+__global__ __launch_bounds__(256) void k_query_topk(QueryArgs A) {
+    __shared__ uint4 s_d[MK_TILE * 2];
+    __shared__ float s_x[MK_TILE], s_y[MK_TILE];
+    __shared__ uint32_t s_o[MK_TILE];
+    __shared__ int s_oct[MK_TILE];
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const float invW = (float)GRID_COLS / (A.max_x - A.min_x), invH = (float)GRID_ROWS / (A.max_y - A.min_y);
+    uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float x = 0, y = 0, r = 0;
+    int lo = -1, hi = -1;
+    if (q < A.nq) {
+        const uint4 *p = (const uint4 *)(A.qdesc + (size_t)q * 32);
+        const uint4 v0 = p[0], v1 = p[1];
+        a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w;
+        a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
+        x = A.qxyr[3 * q];
+        y = A.qxyr[3 * q + 1];
+        r = A.qxyr[3 * q + 2];
+        if (A.qlvl) {
+            lo = A.qlvl[2 * q];
+            hi = A.qlvl[2 * q + 1];
+        }
+    }
+    const bool brute = r < 0.f;
+    const bool check = (lo > 0) || (hi >= 0); /* src/Frame.cpp:245 */
+    uint64_t bk[QK_TOP];
+#pragma unroll
+    for (int k = 0; k < QK_TOP; k++) bk[k] = ~0ull;
+    for (int t0 = 0; t0 < A.n2; t0 += MK_TILE) {
+        const int nt = min(MK_TILE, A.n2 - t0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nt; i += 256) {
+            const OrbKeyPoint kp = A.kps2[t0 + i];
+            const uint4 *src = (const uint4 *)(A.desc2 + (size_t)(t0 + i) * 32);
+            s_d[2 * i] = src[0];
+            s_d[2 * i + 1] = src[1];
+            s_x[i] = kp.x;
+            s_y[i] = kp.y;
+            s_oct[i] = kp.octave;
+            const int ix = (int)round(((double)kp.x - (double)A.min_x) * (double)invW);
+            const int iy = (int)round(((double)kp.y - (double)A.min_y) * (double)invH);
+            s_o[i] = (ix >= 0 && ix < GRID_COLS && iy >= 0 && iy < GRID_ROWS) ? ((uint32_t)(ix * GRID_ROWS + iy) << 16) | (uint32_t)(t0 + i)
+                                                                              : 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        if (q < A.nq) {
+            for (int j = 0; j < nt; j++) {
+                bool cand;
+                uint32_t ord;
+                if (brute) {
+                    cand = true;
+                    ord = (uint32_t)(t0 + j);
+                } else {
+                    ord = s_o[j];
+                    cand = ord != 0xFFFFFFFFu;
+                    if (check) {
+                        const int oc = s_oct[j];
+                        if (oc < lo) cand = false;
+                        if (hi >= 0 && oc > hi) cand = false;
+                    }
+                    cand = cand && fabsf(s_x[j] - x) < r && fabsf(s_y[j] - y) < r;
+                }
+                if (!cand) continue;
+                const int d = hamming256(a, s_d[2 * j], s_d[2 * j + 1]);
+                if (d > A.keep_max_d) continue;
+                const uint64_t key = ((uint64_t)(uint32_t)d << 32) | ord;
+                if (key < bk[QK_TOP - 1]) {
+#pragma unroll
+                    for (int k = QK_TOP - 1; k > 0; k--) bk[k] = key < bk[k - 1] ? bk[k - 1] : (key < bk[k] ? key : bk[k]);
+                    bk[0] = key < bk[0] ? key : bk[0];
+                }
+            }
+        }
+    }
+    if (q < A.nq) {
+#pragma unroll
+        for (int k = 0; k < QK_TOP; k++) A.out[(size_t)q * QK_TOP + k] = bk[k];
+    }
+}
+
+/* projection of the last frame's map points with the current pose: query window and level range per feature
+ * (upstream SearchByProjection, monocular).  A feature that takes no part gets r = 0: no candidate passes |dx| < 0. */
+__global__ void k_project_queries(const OrbKeyPoint *last_kps, const uint8_t *flags, const double *xw, int n, const double *pose12,
+                                  double fx, double fy, double cx, double cy, float min_x, float max_x, float min_y, float max_y,
+                                  const float *scale_factors, int nlevels, float th, float *qxyr, int32_t *qlvl) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float u = 0.f, v = 0.f, r = 0.f;
+    int lo = 0, hi = 0;
+    if (flags[i] & 1) {
+        const double *X = xw + (size_t)i * 3, *R = pose12, *t = pose12 + 9;
+        const double xc = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + t[0];
+        const double yc = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + t[1];
+        const double zc = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + t[2];
+        const double invzc = 1.0 / zc;
+        const int oct = last_kps[i].octave;
+        if (!(invzc < 0) && oct >= 0 && oct < nlevels) {
+            const float uu = (float)(fx * xc * invzc + cx), vv = (float)(fy * yc * invzc + cy);
+            if (!(uu < min_x || uu > max_x) && !(vv < min_y || vv > max_y)) {
+                u = uu;
+                v = vv;
+                r = th * scale_factors[oct];
+                lo = oct - 1;
+                hi = oct + 1;
+            }
+        }
+    }
+    qxyr[3 * i] = u;
+    qxyr[3 * i + 1] = v;
+    qxyr[3 * i + 2] = r;
+    qlvl[2 * i] = lo;
+    qlvl[2 * i + 1] = hi;
+}
+
 /* ------------------------------------------------------------------------------------------------ */
 static OrbErrSlot m_err; /* forwards to orb_last_error() */
 #define MCHK(expr)                                                                         \
@@ -619,6 +759,8 @@ struct OrbMatcher {
     ulonglong2 *d_knn = nullptr;  /* [max_pairs][max_kp] */
     int32_t *d_idx = nullptr;
     uint16_t *d_best = nullptr, *d_second = nullptr;
+    uint8_t *d_scratch = nullptr; /* N4 searches: query parameters and result lists, grown on demand */
+    size_t cap_scratch = 0;
     bool profile = false;
     static const int kProfRing = 64;
     hipEvent_t ev[64][3] = {}; /* start, end, between phase 1 (knn) and phase 2 (resolve) */
@@ -676,6 +818,7 @@ extern "C" void orb_matcher_destroy(OrbMatcher *m) {
     (void)hipFree(m->d_idx);
     (void)hipFree(m->d_best);
     (void)hipFree(m->d_second);
+    (void)hipFree(m->d_scratch);
     for (int r = 0; r < OrbMatcher::kProfRing; r++)
         for (int i = 0; i < 3; i++)
             if (m->ev[r][i]) (void)hipEventDestroy(m->ev[r][i]);
@@ -933,6 +1076,247 @@ extern "C" int orb_features_in_area(OrbMatcher *m, const OrbFrameView *f, const 
     FCHK(hipStreamSynchronize(m->stream));
 #undef FCHK
     cleanup();
+    return ORB_OK;
+}
+
+
+/* ---- SURVEY N4 host side ---------------------------------------------------------------------------------------- */
+static int n4_scratch(OrbMatcher *m, size_t bytes) {
+    if (bytes <= m->cap_scratch) return ORB_OK;
+    if (m->d_scratch) MCHK(hipFree(m->d_scratch));
+    m->d_scratch = nullptr;
+    m->cap_scratch = 0;
+    MCHK(hipMalloc((void **)&m->d_scratch, bytes));
+    m->cap_scratch = bytes;
+    return ORB_OK;
+}
+static inline int host_hamming(const uint8_t *a, const uint8_t *b) {
+    int d = 0;
+    for (int k = 0; k < 4; k++) {
+        uint64_t x, y;
+        memcpy(&x, a + 8 * k, 8);
+        memcpy(&y, b + 8 * k, 8);
+        d += __builtin_popcountll(x ^ y);
+    }
+    return d;
+}
+/* rotation-consistency filter of the reference (src/ORBmatcher.cpp:79-118) over the list of acceptances (bin, feature)
+ * in the order they were made: an entry of a bin outside the three maxima clears its feature and takes one off the
+ * count -- per ENTRY, as upstream's rotHist does: a feature that was given a map point twice (the first point had no
+ * observations) has two entries */
+static int n4_histogram_filter(const std::vector<std::pair<int, int>> &acc, int32_t *match, uint8_t *taken_or_null) {
+    int32_t sizes[HISTO_LENGTH] = {0};
+    for (const auto &e : acc) sizes[e.first]++;
+    int32_t i1 = -1, i2 = -1, i3 = -1;
+    orb_compute_three_maxima(sizes, HISTO_LENGTH, &i1, &i2, &i3);
+    int removed = 0;
+    for (const auto &e : acc)
+        if (e.first != i1 && e.first != i2 && e.first != i3) {
+            match[e.second] = -1;
+            if (taken_or_null) taken_or_null[e.second] = 0;
+            removed++;
+        }
+    return removed;
+}
+static inline int n4_bin(float a1, float a2) {
+    float rot = a1 - a2;
+    if (rot < 0.0f) rot += 360.0f;
+    int bin = (int)roundf(rot * (HISTO_LENGTH / 360.0f));
+    return bin == HISTO_LENGTH ? 0 : bin;
+}
+
+extern "C" int orb_search_by_projection(OrbMatcher *m, const OrbFrameView *cur, const OrbFrameView *last, const uint8_t *last_flags,
+                                        const double *last_xw, const double *Rcw9, const double *tcw3, double fx, double fy,
+                                        double cx, double cy, const float *scale_factors, int nlevels, uint8_t *cur_taken,
+                                        float th, int check_orientation, int32_t *cur_match, int32_t *n_matches) {
+    if (!m || !cur || !last || !n_matches || cur->n < 0 || last->n < 0 || nlevels <= 0 || nlevels > 64 || !scale_factors || !Rcw9 ||
+        !tcw3 || (last->n > 0 && (!last_flags || !last_xw || !last->kps || !last->desc)) ||
+        (cur->n > 0 && (!cur_taken || !cur_match || !cur->kps || !cur->desc)))
+        return ORB_E_INVALID;
+    if (cur->n > m->max_kp || last->n > m->max_kp) return ORB_E_CAPACITY;
+    *n_matches = 0;
+    for (int j = 0; j < cur->n; j++) cur_match[j] = -1;
+    if (cur->n == 0 || last->n == 0) return ORB_OK;
+    MCHK(hipSetDevice(m->device));
+    const int nq = last->n, n2 = cur->n, TH_HIGH = 100;
+    /* scratch: flags | xw | pose | scale factors | qxyr | qlvl | lists */
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_fl = 0, o_xw = al(o_fl + nq), o_pose = al(o_xw + (size_t)nq * 24), o_sf = al(o_pose + 96),
+                 o_q = al(o_sf + (size_t)nlevels * 4), o_lv = al(o_q + (size_t)nq * 12), o_out = al(o_lv + (size_t)nq * 8),
+                 total = al(o_out + (size_t)nq * QK_TOP * 8);
+    int rc;
+    if ((rc = n4_scratch(m, total))) return rc;
+    double pose[12];
+    memcpy(pose, Rcw9, 72);
+    memcpy(pose + 9, tcw3, 24);
+    uint8_t *S = m->d_scratch;
+    MCHK(hipMemcpyAsync(S + o_fl, last_flags, nq, hipMemcpyHostToDevice, m->stream));
+    MCHK(hipMemcpyAsync(S + o_xw, last_xw, (size_t)nq * 24, hipMemcpyHostToDevice, m->stream));
+    MCHK(hipMemcpyAsync(S + o_pose, pose, 96, hipMemcpyHostToDevice, m->stream));
+    MCHK(hipMemcpyAsync(S + o_sf, scale_factors, (size_t)nlevels * 4, hipMemcpyHostToDevice, m->stream));
+    /* frame slot 0 = the current frame (candidates), slot 1 = the last frame (queries) */
+    MCHK(hipMemcpyAsync(m->d_kps, cur->kps, (size_t)n2 * sizeof(OrbKeyPoint), hipMemcpyHostToDevice, m->stream));
+    MCHK(hipMemcpyAsync(m->d_desc, cur->desc, (size_t)n2 * 32, hipMemcpyHostToDevice, m->stream));
+    MCHK(hipMemcpyAsync(m->d_kps + m->max_kp, last->kps, (size_t)nq * sizeof(OrbKeyPoint), hipMemcpyHostToDevice, m->stream));
+    MCHK(hipMemcpyAsync(m->d_desc + (size_t)m->max_kp * 32, last->desc, (size_t)nq * 32, hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(k_project_queries, dim3((nq + 255) / 256), dim3(256), 0, m->stream, m->d_kps + m->max_kp, S + o_fl,
+                       (const double *)(S + o_xw), nq, (const double *)(S + o_pose), fx, fy, cx, cy, cur->min_x, cur->max_x,
+                       cur->min_y, cur->max_y, (const float *)(S + o_sf), nlevels, th, (float *)(S + o_q), (int32_t *)(S + o_lv));
+    QueryArgs A{};
+    A.kps2 = m->d_kps;
+    A.desc2 = m->d_desc;
+    A.n2 = n2;
+    A.qdesc = m->d_desc + (size_t)m->max_kp * 32;
+    A.qxyr = (const float *)(S + o_q);
+    A.qlvl = (const int32_t *)(S + o_lv);
+    A.nq = nq;
+    A.min_x = cur->min_x; A.max_x = cur->max_x; A.min_y = cur->min_y; A.max_y = cur->max_y;
+    A.keep_max_d = TH_HIGH;
+    A.out = (unsigned long long *)(S + o_out);
+    hipLaunchKernelGGL(k_query_topk, dim3((nq + 255) / 256), dim3(256), 0, m->stream, A);
+    MCHK(hipGetLastError());
+    std::vector<unsigned long long> lists((size_t)nq * QK_TOP);
+    std::vector<float> qxyr((size_t)nq * 3);
+    std::vector<int32_t> qlvl((size_t)nq * 2);
+    MCHK(hipMemcpyAsync(lists.data(), S + o_out, lists.size() * 8, hipMemcpyDeviceToHost, m->stream));
+    MCHK(hipMemcpyAsync(qxyr.data(), S + o_q, qxyr.size() * 4, hipMemcpyDeviceToHost, m->stream));
+    MCHK(hipMemcpyAsync(qlvl.data(), S + o_lv, qlvl.size() * 4, hipMemcpyDeviceToHost, m->stream));
+    MCHK(hipStreamSynchronize(m->stream));
+    /* the sequential walk: feature i takes the closest candidate that is still free */
+    const float invW = (float)GRID_COLS / (cur->max_x - cur->min_x), invH = (float)GRID_ROWS / (cur->max_y - cur->min_y);
+    std::vector<std::pair<int, int>> acc; /* (rotation bin, feature) of every acceptance */
+    int nm = 0;
+    for (int i = 0; i < nq; i++) {
+        if (!(last_flags[i] & 1) || !(qxyr[3 * i + 2] > 0.f)) continue;
+        const unsigned long long *L = &lists[(size_t)i * QK_TOP];
+        int best = -1, bestDist = 256, real = 0;
+        for (int k = 0; k < QK_TOP && best < 0; k++) {
+            if (L[k] == ~0ull) break;
+            real++;
+            const int j = (int)(L[k] & 0xFFFFu);
+            if (!cur_taken[j]) {
+                best = j;
+                bestDist = (int)(L[k] >> 32);
+            }
+        }
+        if (best < 0 && real == QK_TOP) {
+            /* all QK_TOP closest candidates were taken by earlier features: look at the whole window (rare) */
+            const float x = qxyr[3 * i], y = qxyr[3 * i + 1], r = qxyr[3 * i + 2];
+            const int lo = qlvl[2 * i], hi = qlvl[2 * i + 1];
+            unsigned long long bestKey = ~0ull;
+            for (int j = 0; j < n2; j++) {
+                if (cur_taken[j]) continue;
+                const OrbKeyPoint &kp = cur->kps[j];
+                const int ix = (int)round(((double)kp.x - (double)cur->min_x) * (double)invW);
+                const int iy = (int)round(((double)kp.y - (double)cur->min_y) * (double)invH);
+                if (ix < 0 || ix >= GRID_COLS || iy < 0 || iy >= GRID_ROWS) continue;
+                if (kp.octave < lo || (hi >= 0 && kp.octave > hi)) continue;
+                if (!(fabsf(kp.x - x) < r && fabsf(kp.y - y) < r)) continue;
+                const int d = host_hamming(last->desc + (size_t)i * 32, cur->desc + (size_t)j * 32);
+                const unsigned long long key = ((unsigned long long)d << 32) | ((unsigned long long)(ix * GRID_ROWS + iy) << 16) | (unsigned)j;
+                if (key < bestKey) bestKey = key;
+            }
+            if (bestKey != ~0ull) {
+                best = (int)(bestKey & 0xFFFFu);
+                bestDist = (int)(bestKey >> 32);
+            }
+        }
+        if (best >= 0 && bestDist <= TH_HIGH) {
+            cur_match[best] = i;
+            if (last_flags[i] & 2) cur_taken[best] = 1;
+            nm++;
+            if (check_orientation) acc.emplace_back(n4_bin(last->kps[i].angle, cur->kps[best].angle), best);
+        }
+    }
+    if (check_orientation) nm -= n4_histogram_filter(acc, cur_match, cur_taken);
+    *n_matches = nm;
+    return ORB_OK;
+}
+
+extern "C" int orb_search_by_bow(OrbMatcher *m, const OrbFrameView *kf, const uint8_t *kf_valid, const OrbFrameView *f, float nnratio,
+                                 int check_orientation, int32_t *f_match, int32_t *n_matches) {
+    if (!m || !kf || !f || !n_matches || kf->n < 0 || f->n < 0 || (kf->n > 0 && (!kf_valid || !kf->kps || !kf->desc)) ||
+        (f->n > 0 && (!f_match || !f->kps || !f->desc)))
+        return ORB_E_INVALID;
+    if (kf->n > m->max_kp || f->n > m->max_kp) return ORB_E_CAPACITY;
+    *n_matches = 0;
+    for (int j = 0; j < f->n; j++) f_match[j] = -1;
+    if (kf->n == 0 || f->n == 0) return ORB_OK;
+    MCHK(hipSetDevice(m->device));
+    const int nq = kf->n, n2 = f->n;
+    /* a candidate beyond TH_LOW matters only as second best, and only while TH_LOW >= d * ratio (cf. k_match_knn) */
+    int keep = TH_LOW;
+    while (keep < 256 && !((float)TH_LOW < (float)(keep + 1) * nnratio)) keep++;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_q = 0, o_out = al((size_t)nq * 12), total = al(o_out + (size_t)nq * QK_TOP * 8);
+    int rc;
+    if ((rc = n4_scratch(m, total))) return rc;
+    uint8_t *S = m->d_scratch;
+    std::vector<float> qxyr((size_t)nq * 3);
+    for (int i = 0; i < nq; i++) {
+        qxyr[3 * i] = qxyr[3 * i + 1] = 0.f;
+        qxyr[3 * i + 2] = kf_valid[i] ? -1.f : 0.f; /* r < 0: every frame feature is a candidate; r = 0: none */
+    }
+    MCHK(hipMemcpyAsync(S + o_q, qxyr.data(), qxyr.size() * 4, hipMemcpyHostToDevice, m->stream));
+    MCHK(hipMemcpyAsync(m->d_kps, f->kps, (size_t)n2 * sizeof(OrbKeyPoint), hipMemcpyHostToDevice, m->stream));
+    MCHK(hipMemcpyAsync(m->d_desc, f->desc, (size_t)n2 * 32, hipMemcpyHostToDevice, m->stream));
+    MCHK(hipMemcpyAsync(m->d_desc + (size_t)m->max_kp * 32, kf->desc, (size_t)nq * 32, hipMemcpyHostToDevice, m->stream));
+    QueryArgs A{};
+    A.kps2 = m->d_kps;
+    A.desc2 = m->d_desc;
+    A.n2 = n2;
+    A.qdesc = m->d_desc + (size_t)m->max_kp * 32;
+    A.qxyr = (const float *)(S + o_q);
+    A.qlvl = nullptr;
+    A.nq = nq;
+    A.min_x = f->min_x; A.max_x = f->max_x; A.min_y = f->min_y; A.max_y = f->max_y;
+    A.keep_max_d = keep;
+    A.out = (unsigned long long *)(S + o_out);
+    hipLaunchKernelGGL(k_query_topk, dim3((nq + 255) / 256), dim3(256), 0, m->stream, A);
+    MCHK(hipGetLastError());
+    std::vector<unsigned long long> lists((size_t)nq * QK_TOP);
+    MCHK(hipMemcpyAsync(lists.data(), S + o_out, lists.size() * 8, hipMemcpyDeviceToHost, m->stream));
+    MCHK(hipStreamSynchronize(m->stream));
+    std::vector<std::pair<int, int>> acc; /* (rotation bin, feature) of every acceptance */
+    int nm = 0;
+    for (int i = 0; i < nq; i++) {
+        if (!kf_valid[i]) continue;
+        const unsigned long long *L = &lists[(size_t)i * QK_TOP];
+        int best = -1, d1 = 256, d2 = 256, real = 0, found = 0;
+        for (int k = 0; k < QK_TOP && found < 2; k++) {
+            if (L[k] == ~0ull) break;
+            real++;
+            const int j = (int)(L[k] & 0xFFFFFFFFu);
+            if (f_match[j] >= 0) continue;
+            if (found == 0) {
+                best = j;
+                d1 = (int)(L[k] >> 32);
+            } else
+                d2 = (int)(L[k] >> 32);
+            found++;
+        }
+        if (found < 2 && real == QK_TOP) { /* the list ran out before two free features turned up: scan them all (rare) */
+            best = -1;
+            d1 = d2 = 256;
+            for (int j = 0; j < n2; j++) {
+                if (f_match[j] >= 0) continue;
+                const int d = host_hamming(kf->desc + (size_t)i * 32, f->desc + (size_t)j * 32);
+                if (d < d1) {
+                    d2 = d1;
+                    d1 = d;
+                    best = j;
+                } else if (d < d2)
+                    d2 = d;
+            }
+        }
+        if (best >= 0 && d1 <= TH_LOW && (float)d1 < nnratio * (float)d2) {
+            f_match[best] = i;
+            nm++;
+            if (check_orientation) acc.emplace_back(n4_bin(kf->kps[i].angle, f->kps[best].angle), best);
+        }
+    }
+    if (check_orientation) nm -= n4_histogram_filter(acc, f_match, nullptr);
+    *n_matches = nm;
     return ORB_OK;
 }
 

@@ -102,3 +102,31 @@ class ORBmatcher:
                                              bounds[0], bounds[1], bounds[2], bounds[3], int(windowSize),
                                              self.mfNNratio, int(self.mbCheckOrientation), d_matches12, d_nmatches,
                                              stream))
+
+    # ---- SURVEY N4 (empty bodies in the reference; upstream semantics, parity unpinned by construction) ----
+    def SearchByProjection(self, cur, last, last_flags, last_xw, Rcw, tcw, fx, fy, cx, cy, scale_factors, cur_taken, th):
+        """include/ORBmatcher.h:24.  cur / last: FrameFeatures; last_flags bit0 = holds a map point and is not an
+        outlier, bit1 = the point has observations; returns (nmatches, cur_match[n_cur], cur_taken[n_cur])."""
+        fl = np.ascontiguousarray(last_flags, np.uint8)
+        xw = np.ascontiguousarray(last_xw, np.float64)
+        R = np.ascontiguousarray(Rcw, np.float64).reshape(9)
+        t = np.ascontiguousarray(tcw, np.float64).reshape(3)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        taken = np.ascontiguousarray(cur_taken, np.uint8).copy()
+        m = np.full(max(len(cur.kps), 1), -1, np.int32)
+        n = C.c_int32(0)
+        vc, vl = cur.view(), last.view()
+        check(self._L.orb_search_by_projection(self._m, C.byref(vc), C.byref(vl), ptr(fl), ptr(xw), ptr(R), ptr(t), fx, fy, cx, cy,
+                                               ptr(sf), len(sf), ptr(taken), float(th), int(self.mbCheckOrientation), ptr(m),
+                                               C.byref(n)))
+        return n.value, m[:len(cur.kps)], taken
+
+    def SearchByBoW(self, kf, kf_valid, frame):
+        """include/ORBmatcher.h:22 with the reference's (absent) vocabulary = one node.  Returns (nmatches, f_match[n_f])."""
+        valid = np.ascontiguousarray(kf_valid, np.uint8)
+        m = np.full(max(len(frame.kps), 1), -1, np.int32)
+        n = C.c_int32(0)
+        vk, vf = kf.view(), frame.view()
+        check(self._L.orb_search_by_bow(self._m, C.byref(vk), ptr(valid), C.byref(vf), self.mfNNratio,
+                                        int(self.mbCheckOrientation), ptr(m), C.byref(n)))
+        return n.value, m[:len(frame.kps)]

@@ -242,11 +242,50 @@ int main(int argc, char **argv) {
         for (int i = 0; i < 30; i++) histo[i].assign((i * 7) % 11, 0);
         int i1 = -1, i2 = -1, i3 = -1;
         matcher.ComputeThreeMaxima(histo, 30, i1, i2, i3);
-        std::vector<MapPoint *> vpMatches;
-        KeyFrame kfDummy;
-        const int nbow = matcher.SearchByBoW(&kfDummy, F1, vpMatches);       /* src/Tracking.cpp:298 */
-        const int nproj = matcher.SearchByProjection(F1, F0, 15.f, true);    /* src/Tracking.cpp:344 */
-        if (dist_self != 0 || dist01 != ref01 || i1 < 0 || histo[i1].size() != 10 || nbow != 0 || nproj != 0) return 5;
+        if (dist_self != 0 || dist01 != ref01 || i1 < 0 || histo[i1].size() != 10) return 5;
+    }
+    Frame::SetCameraPara(win.fx, win.fy, win.cx, win.cy);
+    {
+        /* SearchByProjection (src/Tracking.cpp:344) and SearchByBoW (:298) on the two extracted frames.  Map
+           points for frame 0: its keypoints lifted to depth 4 with the identity pose (three of every four features, every
+           other one with an observation); frame 1 keeps the identity pose, the 2-D motion of the synthetic stream is
+           what the search radius has to absorb */
+        const int nA = (int)F0.mvKeypts.size();
+        std::vector<MapPoint> pts(nA);
+        KeyFrame kf0;
+        kf0.mvUnKeypts = F0.GetUnKeyPts();
+        kf0.mcvDescriptors = F0.mcvDescriptors;
+        for (int i = 0; i < nA; i++) {
+            const cv::KeyPoint &kp = F0.mvKeypts[i];
+            pts[i].mlnId = i;
+            pts[i].SetPos(Eigen::Vector3d((kp.pt.x - win.cx) / win.fx * 4.0, (kp.pt.y - win.cy) / win.fy * 4.0, 4.0));
+            if (i % 2 == 0) pts[i].AddObservation(&kf0, i);
+            if (i % 4 != 3) {
+                F0.mvpMappts[i] = &pts[i];
+                kf0.AddMapPoint(&pts[i], i);
+            }
+        }
+        F0.mvbOutlier[5] = true;
+        ORBmatcher m2(0.9, true);                                            /* src/Tracking.cpp:333 */
+        const int nproj = m2.SearchByProjection(F1, F0, 30.f, true);
+        std::vector<MapPoint *> vpMapPointMatches;
+        ORBmatcher m3(0.7, true);                                            /* src/Tracking.cpp:293 */
+        const int nbow = m3.SearchByBoW(&kf0, F1, vpMapPointMatches);
+        f = fopen((pre + "_n4.bin").c_str(), "wb");
+        const int n1 = (int)F1.mvKeypts.size();
+        const int hdr[3] = {nproj, nbow, n1};
+        fwrite(hdr, 4, 3, f);
+        for (int j = 0; j < n1; j++) {
+            const int id = F1.mvpMappts[j] ? (int)F1.mvpMappts[j]->mlnId : -1;
+            fwrite(&id, 4, 1, f);
+        }
+        for (int j = 0; j < n1; j++) {
+            const int id = vpMapPointMatches[j] ? (int)vpMapPointMatches[j]->mlnId : -1;
+            fwrite(&id, 4, 1, f);
+        }
+        fclose(f);
+        for (int j = 0; j < n1; j++) F1.mvpMappts[j] = nullptr; /* pts goes out of scope */
+        for (int i = 0; i < nA; i++) F0.mvpMappts[i] = nullptr;
     }
 
     /* ---------------- Optimizer ---------------- */
@@ -254,7 +293,6 @@ int main(int argc, char **argv) {
     KeyFrame::fy = win.fy;
     KeyFrame::cx = win.cx;
     KeyFrame::cy = win.cy;
-    Frame::SetCameraPara(win.fx, win.fy, win.cx, win.cy);
     std::vector<double> gba_state, po_state;
     {
         World world(win); /* src/Tracking.cpp:254 */

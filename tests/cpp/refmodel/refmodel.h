@@ -104,6 +104,7 @@ class KeyFrame {
         mvpMappts[id] = p;
     }
     std::vector<cv::KeyPoint> mvUnKeypts;
+    cv::Mat mcvDescriptors; /* include/KeyFrame.h:64 */
     static float fx, fy, cx, cy;
 
   private:
@@ -122,6 +123,7 @@ class MapPoint {
     std::map<KeyFrame *, int> GetObservations() const { return mObservations; }
     std::map<KeyFrame *, int> &GetObservations() { return mObservations; }
     void AddObservation(KeyFrame *pf, int id) { mObservations[pf] = id; }
+    int Obsnums() const { return (int)mObservations.size(); } /* include/MapPoint.h:39 (nObs) */
     long unsigned int mlnId;
 
   private:

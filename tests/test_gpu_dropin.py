@@ -159,6 +159,29 @@ def test_cpp_dropin_every_method(oracle, tmp_path):
     on, om12, _ = oracle.search_for_initialization(k0, d0, k1, d1, (0.0, 640.0, 0.0, 480.0), None, 100, 0.9, True)
     assert mraw[0] == on and on > 100 and np.array_equal(mraw[1:], om12)
 
+    # ---- SURVEY N4 through the C++ classes: SearchByProjection / SearchByBoW fill mvpMappts / vpMatches like the C-ABI ----
+    n4 = np.fromfile(os.path.join(td, "o_n4.bin"), np.int32)
+    nproj, nbow, n1 = n4[:3]
+    cpp_proj, cpp_bow = n4[3:3 + n1], n4[3 + n1:3 + 2 * n1]
+    fxf, fyf, cxf, cyf = (float(np.float32(w[k])) for k in ("fx", "fy", "cx", "cy"))
+    idx0 = np.arange(len(k0))
+    has = idx0 % 4 != 3
+    flags = (has & (idx0 != 5)).astype(np.uint8) | ((has & (idx0 % 2 == 0) & (idx0 != 5)).astype(np.uint8) << 1)
+    xw0 = np.stack([(k0["x"].astype(np.float64) - cxf) / fxf * 4.0, (k0["y"].astype(np.float64) - cyf) / fyf * 4.0,
+                    np.full(len(k0), 4.0)], axis=1)
+    sf = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    sf = np.cumprod(np.concatenate([[np.float32(1.0)], np.full(7, np.float32(1.2))])).astype(np.float32)
+    bnd = (0.0, 640.0, 0.0, 480.0)
+    mm = oa.ORBmatcher(0.9, True, max_keypoints=4096)
+    gn, gm, _ = mm.SearchByProjection(oa.FrameFeatures(k1, d1, bnd), oa.FrameFeatures(k0, d0, bnd), flags, xw0, np.eye(3),
+                                      np.zeros(3), fxf, fyf, cxf, cyf, sf, np.zeros(len(k1), np.uint8), 30.0)
+    mm.close()
+    assert nproj == gn and gn > 30 and np.array_equal(cpp_proj, gm)      # map point id == frame-0 feature index
+    mm = oa.ORBmatcher(0.7, True, max_keypoints=4096)
+    bn, bm = mm.SearchByBoW(oa.FrameFeatures(k0, d0, bnd), has.astype(np.uint8), oa.FrameFeatures(k1, d1, bnd))
+    mm.close()
+    assert nbow == bn and bn > 20 and np.array_equal(cpp_bow, bm)
+
     opt = oa.Optimizer(max_cams=64, max_points=4096, max_obs=32768, max_batch=1)
     # ---- Optimizer::GlobalBundleAdjustemnt(pMap, 20): the reference's graph, gauge free -> gauge-invariant compare ----
     R, t, X = _read_world(os.path.join(td, "o_gba.bin"), NC, NPT)
