@@ -228,6 +228,8 @@ def main():
     rehearse = os.environ.get("BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
+        # several PROCESSES on one GPU: a workgroup team (cooperative launch) assumes it has the device to itself
+        os.environ["ORBSLAM_AMD_BA_TEAM"] = "1"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
