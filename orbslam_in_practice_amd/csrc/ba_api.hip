@@ -481,9 +481,9 @@ __device__ __noinline__ bool ba_chol_solve(const BAWin &w, double *D, const int3
         const int m = elast[kb] - kb; /* tile rows below the diagonal that reach column kb */
         /* diagonal 16 x 16 tile: Cholesky factor and its inverse by ONE wavefront in registers -- lane r < 16 holds row r,
            a pivot or a column entry travels by v_readlane (lane_bcast), every loop is unrolled so that all register
-           indices are static.  Same operations in the same order as the textbook right-looking loop
-           (a[i][k] -= l[i][j] * l[k][j] for j < k <= i), so the factor is bit-identical to the LDS version it replaces,
-           at a third of its time (16 columns x 3 LDS round trips per column before). */
+           indices are static.  The textbook right-looking loop (a[i][k] -= l[i][j] * l[k][j] for j < k <= i), with one
+           reciprocal per column instead of a division per entry; a third of the time of the LDS version it replaces
+           (16 columns x 3 LDS round trips per column there). */
         if (wave == 0) {
             const int rl = lane & 15;
             double a[16];
@@ -493,6 +493,8 @@ __device__ __noinline__ bool ba_chol_solve(const BAWin &w, double *D, const int3
                 for (int k = 0; k < 16; k++) a[k] = Ar[k];
             }
             bool bad = false;
+            double inv[16]; /* 1 / l[j][j]: one division per column; the column scaling and the inverse below multiply by it
+                               (an f64 division is a ~100-cycle dependent chain, and the 16 columns are sequential) */
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 double ajj = lane_bcast(a[j], j);
@@ -501,7 +503,8 @@ __device__ __noinline__ bool ba_chol_solve(const BAWin &w, double *D, const int3
                     ajj = 1.0;
                 }
                 const double pv = sqrt(ajj);
-                a[j] = (rl == j) ? pv : a[j] / pv; /* rows above j hold don't-care values in column j */
+                inv[j] = 1.0 / pv;
+                a[j] = (rl == j) ? pv : a[j] * inv[j]; /* rows above j hold don't-care values in column j */
 #pragma unroll
                 for (int k = j + 1; k < 16; k++) {
                     const double lkj = lane_bcast(a[j], k);
@@ -516,8 +519,7 @@ __device__ __noinline__ bool ba_chol_solve(const BAWin &w, double *D, const int3
 #pragma unroll
                 for (int k = 0; k < 16; k++)
                     if (k < i) v -= lane_bcast(a[k], i) * x[k];
-                const double lii = lane_bcast(a[i], i);
-                x[i] = (i >= rl) ? v / lii : 0.0;
+                x[i] = (i >= rl) ? v * inv[i] : 0.0;
             }
             if (lane < 16) {
                 double *Ar = A + (int64_t)(kb * 16 + rl) * np + kb * 16;
@@ -1047,17 +1049,23 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
     }
 
     double lambda = st[ST_LAMBDA], ni = st[ST_NI]; /* uniform over the team from here on (every sum is a team sum) */
+    double currentChi = 0.0;
+    bool have_chi = false; /* the previous iteration of this launch was accepted: its trial errors and chi2 ARE the current
+                              ones (same edges, same estimate, same summation order), no need to evaluate them again */
     for (int iter = 0; iter < n_iters; iter++) {
     /* ---- computeActiveErrors + activeRobustChi2 ---- */
-    double currentChi = team_sum(eval_chi2_partial(w, D, I, B, w.poses, w.pts, w.err, team), s, team);
-    if (lead && tid == 0 && st[ST_HAVE_CHI0] == 0.0) {
-        st[ST_CHI0] = currentChi;
-        st[ST_HAVE_CHI0] = 1.0;
+    if (!have_chi) {
+        currentChi = team_sum(eval_chi2_partial(w, D, I, B, w.poses, w.pts, w.err, team), s, team);
+        if (lead && tid == 0 && st[ST_HAVE_CHI0] == 0.0) {
+            st[ST_CHI0] = currentChi;
+            st[ST_HAVE_CHI0] = 1.0;
+        }
+        if (G == 1) __syncthreads(); /* (the team's sum already ended in a barrier) */
     }
-    if (G == 1) __syncthreads(); /* (the team's sum already ended in a barrier) */
 
     BA_STAMP(0)
-    /* ---- buildSystem: Hll, bl, W (thread per point) ---- */
+    /* ---- buildSystem: Hll, bl (thread per point; W is written by the camera pass below, which has the same Jacobians
+       in hand and stores whole 144-byte records instead of 18 doubles strided over the lanes) ---- */
     for (int p = gtid; p < w.Np; p += gthreads) {
         double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
         const int e0 = I[w.pt_start + p], e1 = I[w.pt_start + p + 1];
@@ -1084,11 +1092,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
                 er1n = D[w.err + (int64_t)(e + 1) * 2 + 1];
                 infon = D[w.info + e + 1];
             }
-            double *We = D + w.W + (int64_t)e * 18;
-            if (!(f & 1)) {
-                for (int i = 0; i < 18; i++) We[i] = 0.0;
-                continue;
-            }
+            if (!(f & 1)) continue;
             const double *pose = D + w.poses + (int64_t)c * 7;
             const double *X = D + w.pts + (int64_t)p * 3;
             double R[9], pc[3];
@@ -1109,16 +1113,13 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
                 b[a] += Ji[a] * r0 + Ji[3 + a] * r1;
                 for (int bb = 0; bb < 3; bb++) H[a * 3 + bb] += wgt * (Ji[a] * Ji[bb] + Ji[3 + a] * Ji[3 + bb]);
             }
-            const bool free_cam = I[w.slot + c] >= 0;
-            for (int a = 0; a < 6; a++)
-                for (int bb = 0; bb < 3; bb++)
-                    We[a * 3 + bb] = free_cam ? wgt * (Jj[a] * Ji[bb] + Jj[6 + a] * Ji[3 + bb]) : 0.0;
         }
         for (int i = 0; i < 9; i++) D[w.Hll + (int64_t)p * 9 + i] = H[i];
         for (int i = 0; i < 3; i++) D[w.bl + (int64_t)p * 3 + i] = b[i];
     }
     BA_STAMP(1)
-    /* ---- Hpp, bp: one wavefront per free camera, lanes over its edges, shuffle reduction ---- */
+    /* ---- Hpp, bp, W = Hpl: one wavefront per free camera, lanes over its edges, shuffle reduction.  (The W record of an
+       edge of a FIXED camera is never read: the Schur lists, g and the back-substitution only follow free cameras.) ---- */
     for (int c = gwave; c < w.Nc; c += gwaves) {
         const int sl = I[w.slot + c];
         if (sl < 0) continue;
@@ -1129,7 +1130,12 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
         for (int k = k0 + lane; k < k1; k += 64) {
             const int e = I[w.cam_edges + k];
             const uint8_t f = B[w.flags + e];
-            if (!(f & 1)) continue;
+            double2 *We = (double2 *)(D + w.W + (int64_t)e * 18);
+            if (!(f & 1)) { /* switched off: contributes nothing, but its record is read by the block products */
+#pragma unroll
+                for (int i = 0; i < 9; i++) We[i] = double2{0.0, 0.0};
+                continue;
+            }
             const double *X = D + w.pts + (int64_t)I[w.pt + e] * 3;
             double R[9], pc[3];
             quat_to_R(pose, R);
@@ -1151,6 +1157,13 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
             for (int a = 0; a < 6; a++)
                 for (int bb = a; bb < 6; bb++) acc[q++] += wgt * (Jj[a] * Jj[bb] + Jj[6 + a] * Jj[6 + bb]);
             for (int a = 0; a < 6; a++) acc[21 + a] += Jj[a] * r0 + Jj[6 + a] * r1;
+            double wv[18];
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int bb = 0; bb < 3; bb++) wv[a * 3 + bb] = wgt * (Jj[a] * Ji[bb] + Jj[6 + a] * Ji[3 + bb]);
+#pragma unroll
+            for (int i = 0; i < 9; i++) We[i] = double2{wv[2 * i], wv[2 * i + 1]};
         }
         for (int i = 0; i < 27; i++) {
             double v = acc[i];
@@ -1477,6 +1490,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
             lambda *= fmax(1. / 3., alpha);
             ni = 2;
             currentChi = tempChi;
+            have_chi = true;
             for (int i = gtid; i < w.Nc * 7; i += gthreads) D[w.poses + i] = D[w.poses_t + i];
             for (int i = gtid; i < w.Np * 3; i += gthreads) D[w.pts + i] = D[w.pts_t + i];
             for (int i = gtid; i < w.E * 2; i += gthreads) D[w.err + i] = D[w.err_t + i];
