@@ -492,7 +492,10 @@ hipError_t launch_quadtree(const OrbGeom &g, const OrbBuffers &b, int n_frames, 
        side, 0.22 -> 0.11 ms for one 640x480 frame; a big batch has thousands of workgroups in flight and does
        better with the narrow ones */
     if (need > 1024) return launch_qt<2048>(g, b, n_frames, st); /* > 1020 features on one level: the 1024-thread variant */
-    if (n_frames <= 8) return launch_qt<1024>(g, b, n_frames, st);
+    /* up to 32 frames per launch (8 levels x 32 = 256 workgroups = one per CU) the wide variant wins -- 64 frames of
+       1280x720 per rank, BASELINE configs[3]: 43.0 -> 57.0 k frames/s; at 128 frames per launch it loses (61.0 -> 57.3) */
+    static const int wide_max = getenv("ORBSLAM_AMD_QT_WIDE_MAX") ? atoi(getenv("ORBSLAM_AMD_QT_WIDE_MAX")) : 32;
+    if (n_frames <= wide_max) return launch_qt<1024>(g, b, n_frames, st);
     if (need <= 256) return launch_qt<256>(g, b, n_frames, st);
     if (need <= 512) return launch_qt<512>(g, b, n_frames, st);
     return launch_qt<1024>(g, b, n_frames, st);
