@@ -2127,7 +2127,10 @@ static int ba_choose_team(BASolver *s, int nwin, int maxE) {
        per CU too high (MI355X_MICROARCH.md, correctness boundaries) and a team barrier would then wait for a workgroup
        that is not resident. */
     const int resident = s->cu_count;
-    int want = s->force_team > 0 ? s->force_team : std::max(1, maxE / 768);
+    /* measured (tools/ba_probe.py, one window in flight): 28 k edges 19.5 / 14.0 / 11.5 / 11.9 / 15.0 ms with 4 / 8 / 16 /
+       32 / 64 workgroups, 11 k edges 9.2 / 7.3 / 6.8 / 7.9 ms with 4 / 8 / 16 / 32, 2.9 k edges 4.5 / 4.1 / 4.0 ms with
+       1 / 4 / 8: a barrier costs more the more workgroups arrive at its counter, and past 16 that outweighs the split */
+    int want = s->force_team > 0 ? s->force_team : std::max(1, std::min(16, maxE / 700));
     int G = 1;
     while (G * 2 <= BA_GMAX && G * 2 <= want && (long)nwin * (G * 2) <= resident) G *= 2;
     return G;

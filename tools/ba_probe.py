@@ -13,10 +13,11 @@ import orbslam_in_practice_amd as oa  # noqa: E402
 from orbslam_in_practice_amd import synth  # noqa: E402
 
 batch = int(os.environ.get("BATCH", "256"))
+NC, NP = int(os.environ.get("NC", "100")), int(os.environ.get("NP", "5000"))
 for nu in [int(a) for a in sys.argv[1:]] or [4, 32]:
-    uniq = [synth.make_ba_window(900 + i, 100, 5000) for i in range(nu)]
+    uniq = [synth.make_ba_window(900 + i, NC, NP) for i in range(nu)]
     wins = [uniq[i % nu] for i in range(batch)]
-    opt = oa.Optimizer(max_cams=100, max_points=5000, max_obs=40000, max_batch=batch)
+    opt = oa.Optimizer(max_cams=NC, max_points=NP, max_obs=10 * NP, max_batch=batch)
     opt.solve_batch(wins, (5, 10))
     opt.set_profiling(True)
     t0 = time.perf_counter()
