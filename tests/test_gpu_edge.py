@@ -172,3 +172,42 @@ def test_wide_frames_return_more_than_their_budget(oracle, w, h, nf, nl, nb):
         for (k, d), (ok, od) in zip(got, want):
             assert np.array_equal(k, ok) and np.array_equal(d, od)
         e.close()
+
+
+def test_extractors_on_concurrent_host_threads(oracle):
+    """one extractor handle per host thread (the documented model), different frame sizes, growing buffers and changing
+    geometry while the others run: every thread's results equal the oracle's (the buffer-generation sink and
+    the per-device LDS limits were process-wide and unsynchronised)"""
+    import threading
+    import orbslam_in_practice_amd as oa
+    from orbslam_in_practice_amd import synth
+    shapes = [(640, 480, 1000), (320, 240, 500), (800, 600, 1500)]
+    frames = {s: [synth.make_frame(900 + 10 * i + k, s[0], s[1], n_shapes=s[0] * s[1] // 100) for k in range(4)]
+              for i, s in enumerate(shapes)}
+    refs = {}
+    for s in shapes:
+        o = oracle.OrbOracle(s[2], 1.2, 8, 20, 7)
+        refs[s] = [o.extract(f) for f in frames[s]]
+    errors = []
+
+    def worker(s, order):
+        try:
+            # created small on purpose: the first call of every size has to grow the buffers and rebuild the geometry
+            e = oa.ORBextractor(s[2], 1.2, 8, 20, 7, max_w=64, max_h=64, max_batch=1)
+            for rep in range(3):
+                for k in order:
+                    kp, d = e(frames[s][k])
+                    rk, rd = refs[s][k]
+                    if not (np.array_equal(kp, rk) and np.array_equal(d, rd)):
+                        errors.append((s, rep, k))
+            e.close()
+        except Exception as ex:  # noqa: BLE001
+            errors.append((s, repr(ex)))
+
+    threads = [threading.Thread(target=worker, args=(s, [0, 1, 2, 3] if i % 2 == 0 else [3, 2, 1, 0]))
+               for i, s in enumerate(shapes)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errors, errors
