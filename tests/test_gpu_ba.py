@@ -373,3 +373,41 @@ def test_ba_more_than_256_free_cameras(oracle):
     assert _rel(got2["points"], ref["points"]) < REL
     assert _rel(got2["poses"][inv][:, 4:], ref["poses"][:, 4:]) < REL
     o.close()
+
+
+def test_ba_point_seen_by_every_camera_takes_the_list_path(opt, oracle):
+    """a point observed by all 100 keyframes has 5050 contributions to the reduced system -- more than a point chunk of
+    the LDS-staged Schur pass holds: such a window falls back to the per-block lists (also inside a batch) and still
+    agrees with the oracle"""
+    from orbslam_in_practice_amd import synth
+    ws = []
+    for seed in (61, 62):
+        w = synth.make_ba_window(seed, 100, 600)
+        w["fixed"][:2] = 1
+        q, t = w["gt_poses"][:, :4], w["gt_poses"][:, 4:]
+        X = w["gt_points"][0]
+        rng = np.random.default_rng(seed)
+        have = set(w["cam_idx"][w["pt_idx"] == 0].tolist())
+        add_c, add_o = [], []
+        for c in range(100):
+            if c in have:
+                continue
+            qw, qx, qy, qz = q[c]
+            R = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)],
+                          [2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)],
+                          [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]])
+            pc = R @ X + t[c]
+            if pc[2] <= 0.1:
+                continue
+            add_c.append(c)
+            add_o.append([w["fx"] * pc[0] / pc[2] + w["cx"] + rng.normal(0, 1), w["fy"] * pc[1] / pc[2] + w["cy"] + rng.normal(0, 1)])
+        w["cam_idx"] = np.concatenate([w["cam_idx"], np.array(add_c, np.int32)])
+        w["pt_idx"] = np.concatenate([w["pt_idx"], np.zeros(len(add_c), np.int32)])
+        w["obs"] = np.concatenate([w["obs"], np.array(add_o).reshape(-1, 2)])
+        w["inv_sigma2"] = np.concatenate([w["inv_sigma2"], np.ones(len(add_c))])
+        assert (w["pt_idx"] == 0).sum() > 91          # k (k + 1) / 2 > 4096
+        ws.append(w)
+    got = opt.solve_batch(ws, (5, 10))
+    for w, g in zip(ws, got):
+        ref = oracle.ba_solve(w, rounds=(5, 10))
+        _check_estimates(g, ref)
