@@ -45,10 +45,12 @@
 #define BA_W (BA_T / 64)
 #define BA_MAX_N 1536 /* reduced system size (6 * free cameras) whose PCG vectors fit the static LDS arrays */
 #define BA_GMAX 64    /* most workgroups that may team up on one window */
-#define BA_CHUNK_E 512 /* Schur staging: edges (W records, 144 B) of one point chunk held in LDS */
-#define BA_CHUNK_P 128 /* ... and its points (Dinv 72 B, tv 24 B) */
-#define BA_CHUNK_C 4096 /* ... and its contribution list (packed local edge pairs, ints) */
+#define BA_CHUNK_E 368 /* Schur staging: edges (W records, 144 B) of one point chunk held in LDS; sized so that TWO
+                          workgroups' tiles (BA_CHUNK_DOUBLES: 77.7 KB) fit the 160 KB of a CU (k_ba_ph_schur2) */
+#define BA_CHUNK_P 96  /* ... and its points (Dinv 72 B, tv 24 B) */
+#define BA_CHUNK_C 2560 /* ... and its contribution list (packed local edges + point, ints) */
 #define BA_CHUNK_B 256  /* ... and the blocks it touches (id, list start) */
+#define BA_CH_DESC 16   /* ints per chunk descriptor */
 #define BA_CHUNK_DOUBLES (BA_CHUNK_E * 18 + BA_CHUNK_P * 12 + BA_CHUNK_E / 2 + BA_CHUNK_C / 2 + BA_CHUNK_B + BA_CHUNK_E / 2 + 32)
 
 static OrbErrSlot b_err; /* forwards to orb_last_error() */
@@ -69,11 +71,13 @@ struct BAWin {
     /* doubles */
     int64_t poses, poses_t, pts, pts_t, obs, info, err, err_t, W, tv, Hpp, bp, Hll, bl, Dinv, S, g, Minv, x, xl, st;
     int64_t A, Linv; /* dense reduced system (np x np) and inverse diagonal blocks of its Cholesky factor */
+    int64_t S2, g2;  /* second accumulator of the Schur products and of g (phase-kernel path: the window's chunks are split
+                        over two workgroups; the Cholesky assembly adds S and S2, g and g2); chunked windows only */
     /* ints */
     int64_t cam, pt, pt_start, cam_start, cam_edges, slot, blk_row, blk_col, blk_diag, blk_mirror, blk_upper, blk_rowid, con_start, con_e1, con_e2;
     int64_t ch_first, ch_last; /* Cholesky envelope per 16-row tile: first tile column of tile row i (non-decreasing), last tile row that reaches tile column k */
-    /* batch path of the Schur complement: point chunks (12 ints each: edge range, point range, block range, camera
-       range, start and length of the chunk's contribution list and of its camera edge list), per chunk the blocks it touches with their contribution lists (local edge pair packed a | b << 16) and
+    /* batch path of the Schur complement: point chunks (BA_CH_DESC ints each: edge range, point range, block range, camera
+       range, start and length of the chunk's contribution list and of its camera edge list), per chunk the blocks it touches with their contribution lists (local edges a, b and local point p packed a | b << 9 | p << 18) and
        the free cameras it touches with their local edge lists; nchunks == 0: list path only */
     int nchunks, pad_;
     int64_t ch_desc, cb_blk, cb_start, cb_con, cg_slot, cg_start, cg_edge;
@@ -86,6 +90,9 @@ struct BAWin {
 /* LM state (doubles at D[st + i]) */
 enum { ST_LAMBDA = 0, ST_NI, ST_CHI, ST_CHI0, ST_ITERS, ST_SOLVES, ST_TERM, ST_ROUND_IT, ST_HAVE_CHI0, ST_PCG_ITERS,
        ST_ABORT, /* a team barrier gave up waiting (never expected; the host turns it into an error) */
+       /* state machine of the phase-kernel batch path (k_ba_ph_*): where the window stands in its optimize() round */
+       ST_PH,      /* 0: an LM iteration starts (build), 1: same iteration, next trial (solve again), 2: round over */
+       ST_QMAX, ST_HAVECHI, ST_OK2, ST_BUDGET, ST_FIRST, ST_ACCEPT,
        ST_T0, /* 10 phase timers + 6 sub-timers of the chunked Schur pass (profile mode), 100 MHz ticks */
        ST_COUNT = ST_T0 + 24 };
 
@@ -243,7 +250,7 @@ struct BAShared {
     double bc[8];
 };
 
-__device__ __forceinline__ double block_sum(double v, BAShared &s) {
+template <class SH> __device__ __forceinline__ double block_sum(double v, SH &s) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); /* uniform: scalar unit */
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -254,7 +261,7 @@ __device__ __forceinline__ double block_sum(double v, BAShared &s) {
     for (int w = 0; w < BA_W; w++) t += s.red[w];
     return t;
 }
-__device__ __forceinline__ double block_max(double v, BAShared &s) {
+template <class SH> __device__ __forceinline__ double block_max(double v, SH &s) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); /* uniform: scalar unit */
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
@@ -429,7 +436,7 @@ __device__ int g_chol_scalar = 0; /* debug: 1 = plain loops instead of MFMA */
  * lower triangle -- and pad the diagonal with ones.  Strided over the whole team (gtid of gthreads; rows by gwave of
  * gwaves): disjoint writers, except that a block overwrites zeros of the first loop, hence the barrier in between
  * (the caller supplies it as a callable: __syncthreads() or the team barrier). */
-template <class Sync>
+template <bool TWO = false, class Sync>
 __device__ __forceinline__ void ba_chol_assemble(const BAWin &w, double *D, const int32_t *I, int n, int gtid, int gthreads, int gwave,
                                                  int gwaves, Sync &&sync) {
     const int np = (n + 15) & ~15, lane = threadIdx.x & 63;
@@ -443,7 +450,7 @@ __device__ __forceinline__ void ba_chol_assemble(const BAWin &w, double *D, cons
     for (int i = gtid; i < w.nnzb * 36; i += gthreads) {
         const int bk = i / 36, e = i - bk * 36;
         const int br = I[w.blk_rowid + bk], bc = I[w.blk_col + bk];
-        if (bc >= br) A[(int64_t)(bc * 6 + e % 6) * np + br * 6 + e / 6] = D[w.S + i];
+        if (bc >= br) A[(int64_t)(bc * 6 + e % 6) * np + br * 6 + e / 6] = TWO ? D[w.S + i] + D[w.S2 + i] : D[w.S + i];
     }
     for (int i = n + gtid; i < np; i += gthreads) A[(int64_t)i * np + i] = 1.0; /* identity padding */
 }
@@ -453,7 +460,8 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
     return __hiloint2double(hi, lo);
 }
-__device__ __noinline__ bool ba_chol_solve(const BAWin &w, double *D, const int32_t *I, int n, double *dyn, BAShared &s, int debug) {
+template <bool TWO = false>
+__device__ __noinline__ bool ba_chol_solve(const BAWin &w, double *D, const int32_t *I, int n, double *dyn, double *bad_flag, int debug) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); /* uniform: scalar unit */
     unsigned long long tp = debug ? __builtin_amdgcn_s_memrealtime() : 0ull;
 #define CH_STAMP(k)                                                         \
@@ -473,7 +481,7 @@ __device__ __noinline__ bool ba_chol_solve(const BAWin &w, double *D, const int3
     double *sl = sd + 16 * CH_LD;           /* its inverse, 16 x CH_LD      */
     double *z = sl + 16 * CH_LD;            /* right-hand side / solution   */
     const int32_t *efirst = I + w.ch_first, *elast = I + w.ch_last;
-    if (tid == 0) s.bc[0] = 0.0;
+    if (tid == 0) bad_flag[0] = 0.0;
     __syncthreads();
     CH_STAMP(0)
     /* ---- factorisation ---- */
@@ -487,14 +495,16 @@ __device__ __noinline__ bool ba_chol_solve(const BAWin &w, double *D, const int3
         if (wave == 0) {
             const int rl = lane & 15;
             double a[16];
+            unsigned long long tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0;
+            if (debug) tq0 = __builtin_amdgcn_s_memrealtime();
             {
                 const double *Ar = A + (int64_t)(kb * 16 + rl) * np + kb * 16;
 #pragma unroll
                 for (int k = 0; k < 16; k++) a[k] = Ar[k];
             }
+            if (debug) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tq1 = __builtin_amdgcn_s_memrealtime(); }
             bool bad = false;
-            double inv[16]; /* 1 / l[j][j]: one division per column; the column scaling and the inverse below multiply by it
-                               (an f64 division is a ~100-cycle dependent chain, and the 16 columns are sequential) */
+            double inv[16]; /* 1 / l[j][j]: the column scaling and the inverse below multiply by it */
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 double ajj = lane_bcast(a[j], j);
@@ -502,15 +512,24 @@ __device__ __noinline__ bool ba_chol_solve(const BAWin &w, double *D, const int3
                     bad = true;
                     ajj = 1.0;
                 }
-                const double pv = sqrt(ajj);
-                inv[j] = 1.0 / pv;
-                a[j] = (rl == j) ? pv : a[j] * inv[j]; /* rows above j hold don't-care values in column j */
+                /* 1 / sqrt(ajj) from v_rsq_f64 (about 2^-23) and two Newton steps, the pivot as ajj * that: 7 dependent
+                   f64 operations where sqrt() followed by a division is about 30 -- and the 16 columns are sequential */
+                double r = __builtin_amdgcn_rsq(ajj);
+#pragma unroll
+                for (int nr = 0; nr < 2; nr++) {
+                    const double e = __builtin_fma(-(ajj * r), r, 1.0);
+                    r = __builtin_fma(0.5 * r, e, r);
+                }
+                inv[j] = r;
+                const double pv = ajj * r;
+                a[j] = (rl == j) ? pv : a[j] * r; /* rows above j hold don't-care values in column j */
 #pragma unroll
                 for (int k = j + 1; k < 16; k++) {
                     const double lkj = lane_bcast(a[j], k);
                     a[k] -= a[j] * lkj;
                 }
             }
+            if (debug) { asm volatile("" : "+v"(a[15])); tq2 = __builtin_amdgcn_s_memrealtime(); }
             /* column rl of L^-1 by forward substitution: x[i] = (delta - sum_{k<i} l[i][k] x[k]) / l[i][i] */
             double x[16];
 #pragma unroll
@@ -520,6 +539,12 @@ __device__ __noinline__ bool ba_chol_solve(const BAWin &w, double *D, const int3
                 for (int k = 0; k < 16; k++)
                     if (k < i) v -= lane_bcast(a[k], i) * x[k];
                 x[i] = (i >= rl) ? v * inv[i] : 0.0;
+            }
+            if (debug) { asm volatile("" : "+v"(x[15])); tq3 = __builtin_amdgcn_s_memrealtime(); }
+            if (debug && lane == 0) {
+                D[w.st + ST_T0 + 17] += (double)(tq1 - tq0);
+                D[w.st + ST_T0 + 14] += (double)(tq2 - tq1);
+                D[w.st + ST_T0 + 15] += (double)(tq3 - tq2);
             }
             if (lane < 16) {
                 double *Ar = A + (int64_t)(kb * 16 + rl) * np + kb * 16;
@@ -531,7 +556,7 @@ __device__ __noinline__ bool ba_chol_solve(const BAWin &w, double *D, const int3
                     Li[kb * 256 + i * 16 + rl] = x[i];
                 }
             }
-            if (bad && lane == 0) s.bc[0] = 1.0;
+            if (bad && lane == 0) bad_flag[0] = 1.0;
         }
         __syncthreads();
         CH_STAMP(2)
@@ -601,9 +626,9 @@ __device__ __noinline__ bool ba_chol_solve(const BAWin &w, double *D, const int3
         __syncthreads();
         CH_STAMP(4)
     }
-    const bool ok = s.bc[0] == 0.0;
+    const bool ok = bad_flag[0] == 0.0;
     /* ---- forward substitution L y = g ---- */
-    for (int i = tid; i < np; i += BA_T) z[i] = (i < n) ? D[w.g + i] : 0.0;
+    for (int i = tid; i < np; i += BA_T) z[i] = (i < n) ? (TWO ? D[w.g + i] + D[w.g2 + i] : D[w.g + i]) : 0.0;
     __syncthreads();
     for (int kb = 0; kb < nb; kb++) {
         double v = 0.0;
@@ -684,9 +709,9 @@ __device__ __forceinline__ void group16_reduce36(const double *acc, int l16, dou
 __device__ __noinline__ void ba_schur_chunked(const BAWin &w, double *D, const int32_t *I, double *ba_dyn, int debug) {
 #pragma clang fp contract(fast) /* the block products as FMAs: half the f64 instructions; estimates are compared at 1e-5 */
     const int tid = threadIdx.x;
-    unsigned long long tp = debug ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    unsigned long long tp = (debug & 3) ? __builtin_amdgcn_s_memrealtime() : 0ull; /* bits 4..: timing experiments that skip parts */
 #define SCH_STAMP(k)                                                        \
-    if (debug) {                                                            \
+    if (debug & 3) {                                                          \
         __syncthreads();                                                    \
         if (tid == 0) {                                                     \
             const unsigned long long tn = __builtin_amdgcn_s_memrealtime(); \
@@ -697,7 +722,7 @@ __device__ __noinline__ void ba_schur_chunked(const BAWin &w, double *D, const i
     /* LDS tiles of one chunk */
     double *sW = ba_dyn, *sD = sW + BA_CHUNK_E * 18, *sT = sD + BA_CHUNK_P * 9;
     int32_t *sP = (int32_t *)(sT + BA_CHUNK_P * 3); /* edge -> local point                        */
-    int32_t *sC = sP + BA_CHUNK_E;                  /* contribution lists (a | b << 16)            */
+    int32_t *sC = sP + BA_CHUNK_E;                  /* contribution lists (a | b << 9 | p << 18)   */
     int32_t *sB = sC + BA_CHUNK_C;                  /* blocks touched                              */
     int32_t *sBS = sB + BA_CHUNK_B;                 /* their list starts, relative to the chunk's  */
     int32_t *sG = sBS + BA_CHUNK_B + 8;             /* local edges by free camera                  */
@@ -705,10 +730,11 @@ __device__ __noinline__ void ba_schur_chunked(const BAWin &w, double *D, const i
     double2 rW[BA_CH_WPT];
     double rD[BA_CH_DPT], rT;
     int32_t rP, rC[BA_CH_CPT], rB, rBS, rG;
+    static_assert(BA_CHUNK_E <= 512 && BA_CHUNK_P <= 8192, "a | b << 9 | p << 18 in 32 bits");
     static_assert(BA_CHUNK_E <= BA_T && BA_CHUNK_P * 3 <= BA_T && BA_CHUNK_B + 1 <= BA_T && BA_CHUNK_C % BA_T == 0,
                   "one element per thread for the small tiles");
     auto fetch = [&](int ch) { /* chunk ch -> registers, every load issued back to back */
-        const int32_t *cd = I + w.ch_desc + ch * 12;
+        const int32_t *cd = I + w.ch_desc + ch * BA_CH_DESC;
         const int e0 = cd[0], ne = cd[1] - cd[0], p0 = cd[2], npnt = cd[3] - cd[2], cb0 = cd[4], ncb = cd[5] - cd[4];
         const int c0 = cd[8], nc = cd[9], g0 = cd[10], ng = cd[11];
         const double2 *src = (const double2 *)(D + w.W + (int64_t)e0 * 18); /* 144-B records: 16-B aligned */
@@ -754,7 +780,7 @@ __device__ __noinline__ void ba_schur_chunked(const BAWin &w, double *D, const i
     };
     fetch(0);
     for (int ch = 0; ch < w.nchunks; ch++) {
-        const int32_t *cd = I + w.ch_desc + ch * 12;
+        const int32_t *cd = I + w.ch_desc + ch * BA_CH_DESC;
         const int ncb = cd[5] - cd[4], cg0 = cd[6], ncg = cd[7] - cd[6], g0 = cd[10];
         commit();
         __syncthreads();
@@ -772,8 +798,8 @@ __device__ __noinline__ void ba_schur_chunked(const BAWin &w, double *D, const i
             for (int i = 0; i < 36; i++) acc[i] = 0.0;
             for (int k = k0 + l16; k < k1; k += 16) {
                 const uint32_t ab = (uint32_t)sC[k];
-                const int a = ab & 0xFFFF, b = ab >> 16;
-                const double *Wa = sW + a * 18, *Wb = sW + b * 18, *Iv = sD + sP[a] * 9;
+                const int a = ab & 511, b = (ab >> 9) & 511;
+                const double *Wa = sW + a * 18, *Wb = sW + b * 18, *Iv = sD + (ab >> 18) * 9;
                 double y[18], ww[18];
 #pragma unroll
                 for (int r = 0; r < 6; r++) {
@@ -800,7 +826,7 @@ __device__ __noinline__ void ba_schur_chunked(const BAWin &w, double *D, const i
         }
         SCH_STAMP(2)
         /* g: group g takes cameras g, g + 32, ... of the chunk */
-        for (int u = grp; u < ncg; u += BA_T / 16) {
+        for (int u = (debug & 64) ? ncg : grp; u < ncg; u += BA_T / 16) {
             const int sl = I[w.cg_slot + cg0 + u];
             const int k0 = I[w.cg_start + cg0 + u] - g0, k1 = I[w.cg_start + cg0 + u + 1] - g0;
             double acc[6] = {0, 0, 0, 0, 0, 0};
@@ -1001,6 +1027,227 @@ __device__ __noinline__ bool ba_pcg_global(const BAWin &w, double *D, const int3
     return ok;
 }
 
+/* ---- phases of one LM iteration, shared by the fused kernel (k_ba_iteration: a window's whole optimize() round in one
+ * launch, teams) and the phase kernels of the batch path (k_ba_ph_*).  Each is strided over gthreads threads (gwaves
+ * wavefronts) of which this thread is gtid (this wavefront gwave). ---- */
+/* buildSystem: Hll, bl (thread per point; W is written by the camera pass, which has the same Jacobians in hand and
+   stores whole 144-byte records instead of 18 doubles strided over the lanes) */
+__device__ __forceinline__ void ba_phase_hll(const BAWin &w, double *D, const int32_t *I, const uint8_t *B, int gtid, int gthreads) {
+    for (int p = gtid; p < w.Np; p += gthreads) {
+        double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+        const int e0 = I[w.pt_start + p], e1 = I[w.pt_start + p + 1];
+        /* software pipeline over the point's edges: flag, camera id, residual and information of the NEXT edge are
+           fetched while the current one waits for its pose (one dependent round trip per edge instead of three) */
+        uint8_t fn = 0;
+        int cn = 0;
+        double er0n = 0, er1n = 0, infon = 0;
+        if (e0 < e1) {
+            fn = B[w.flags + e0];
+            cn = I[w.cam + e0];
+            er0n = D[w.err + (int64_t)e0 * 2];
+            er1n = D[w.err + (int64_t)e0 * 2 + 1];
+            infon = D[w.info + e0];
+        }
+        for (int e = e0; e < e1; e++) {
+            const uint8_t f = fn;
+            const int c = cn;
+            const double er0 = er0n, er1 = er1n, info = infon;
+            if (e + 1 < e1) {
+                fn = B[w.flags + e + 1];
+                cn = I[w.cam + e + 1];
+                er0n = D[w.err + (int64_t)(e + 1) * 2];
+                er1n = D[w.err + (int64_t)(e + 1) * 2 + 1];
+                infon = D[w.info + e + 1];
+            }
+            if (!(f & 1)) continue;
+            const double *pose = D + w.poses + (int64_t)c * 7;
+            const double *X = D + w.pts + (int64_t)p * 3;
+            double R[9], pc[3];
+            quat_to_R(pose, R);
+            pc[0] = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + pose[4];
+            pc[1] = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + pose[5];
+            pc[2] = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + pose[6];
+            double Ji[6], Jj[12];
+            jacobians(pose, pc, w.fx, w.fy, Ji, Jj);
+            double wgt = info, r0 = -info * er0, r1 = -info * er1;
+            if (f & 2) {
+                const double rw = huber_w((er0 * er0 + er1 * er1) * info, w.delta);
+                wgt *= rw;
+                r0 *= rw;
+                r1 *= rw;
+            }
+            for (int a = 0; a < 3; a++) {
+                b[a] += Ji[a] * r0 + Ji[3 + a] * r1;
+                for (int bb = 0; bb < 3; bb++) H[a * 3 + bb] += wgt * (Ji[a] * Ji[bb] + Ji[3 + a] * Ji[3 + bb]);
+            }
+        }
+        for (int i = 0; i < 9; i++) D[w.Hll + (int64_t)p * 9 + i] = H[i];
+        for (int i = 0; i < 3; i++) D[w.bl + (int64_t)p * 3 + i] = b[i];
+    }
+}
+/* Hpp, bp, W = Hpl: one wavefront per free camera, lanes over its edges, shuffle reduction.  (The W record of an edge of a
+   FIXED camera is never read: the Schur lists, g and the back-substitution only follow free cameras.) */
+__device__ __forceinline__ void ba_phase_hpp(const BAWin &w, double *D, const int32_t *I, const uint8_t *B, int gwave, int gwaves, int lane) {
+    for (int c = gwave; c < w.Nc; c += gwaves) {
+        const int sl = I[w.slot + c];
+        if (sl < 0) continue;
+        double acc[27];
+        for (int i = 0; i < 27; i++) acc[i] = 0.0;
+        const int k0 = I[w.cam_start + c], k1 = I[w.cam_start + c + 1];
+        const double *pose = D + w.poses + (int64_t)c * 7;
+        for (int k = k0 + lane; k < k1; k += 64) {
+            const int e = I[w.cam_edges + k];
+            const uint8_t f = B[w.flags + e];
+            double2 *We = (double2 *)(D + w.W + (int64_t)e * 18);
+            if (!(f & 1)) { /* switched off: contributes nothing, but its record is read by the block products */
+    #pragma unroll
+                for (int i = 0; i < 9; i++) We[i] = double2{0.0, 0.0};
+                continue;
+            }
+            const double *X = D + w.pts + (int64_t)I[w.pt + e] * 3;
+            double R[9], pc[3];
+            quat_to_R(pose, R);
+            pc[0] = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + pose[4];
+            pc[1] = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + pose[5];
+            pc[2] = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + pose[6];
+            double Ji[6], Jj[12];
+            jacobians(pose, pc, w.fx, w.fy, Ji, Jj);
+            const double er0 = D[w.err + (int64_t)e * 2], er1 = D[w.err + (int64_t)e * 2 + 1];
+            const double info = D[w.info + e];
+            double wgt = info, r0 = -info * er0, r1 = -info * er1;
+            if (f & 2) {
+                const double rw = huber_w((er0 * er0 + er1 * er1) * info, w.delta);
+                wgt *= rw;
+                r0 *= rw;
+                r1 *= rw;
+            }
+            int q = 0;
+            for (int a = 0; a < 6; a++)
+                for (int bb = a; bb < 6; bb++) acc[q++] += wgt * (Jj[a] * Jj[bb] + Jj[6 + a] * Jj[6 + bb]);
+            for (int a = 0; a < 6; a++) acc[21 + a] += Jj[a] * r0 + Jj[6 + a] * r1;
+            double wv[18];
+    #pragma unroll
+            for (int a = 0; a < 6; a++)
+    #pragma unroll
+                for (int bb = 0; bb < 3; bb++) wv[a * 3 + bb] = wgt * (Jj[a] * Ji[bb] + Jj[6 + a] * Ji[3 + bb]);
+    #pragma unroll
+            for (int i = 0; i < 9; i++) We[i] = double2{wv[2 * i], wv[2 * i + 1]};
+        }
+        for (int i = 0; i < 27; i++) {
+            double v = acc[i];
+    #pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            acc[i] = v;
+        }
+        if (lane == 0) {
+            int q = 0;
+            for (int a = 0; a < 6; a++)
+                for (int bb = a; bb < 6; bb++) {
+                    D[w.Hpp + (int64_t)sl * 36 + a * 6 + bb] = acc[q];
+                    D[w.Hpp + (int64_t)sl * 36 + bb * 6 + a] = acc[q];
+                    q++;
+                }
+            for (int a = 0; a < 6; a++) D[w.bp + (int64_t)sl * 6 + a] = acc[21 + a];
+        }
+    }
+}
+/* computeLambdaInit: this thread's share of the largest diagonal entry of the Hessian */
+__device__ __forceinline__ double ba_phase_lambda0(const BAWin &w, const double *D, int gtid, int gthreads) {
+    double m = 0;
+    for (int i = gtid; i < w.Ncf * 6; i += gthreads) m = fmax(m, fabs(D[w.Hpp + (int64_t)(i / 6) * 36 + (i % 6) * 7]));
+    for (int i = gtid; i < w.Np * 3; i += gthreads) m = fmax(m, fabs(D[w.Hll + (int64_t)(i / 3) * 9 + (i % 3) * 4]));
+    return m;
+}
+/* Dinv = (Hll + lambda I)^-1 and tv = Dinv bl (thread per point); S := Hpp + lambda I on its diagonal blocks, g := bp.
+   Y = W Dinv is never stored: the Schur products form it in registers from W and Dinv (54 FMAs per contribution against
+   a 144-byte record written, read back ~6 times and mostly missing every cache when 256 windows run at once). */
+__device__ __forceinline__ void ba_phase_dinv(const BAWin &w, double *D, const int32_t *I, double lambda, int gtid, int gthreads) {
+    for (int p = gtid; p < w.Np; p += gthreads) {
+        double Dm[9];
+        for (int i = 0; i < 9; i++) Dm[i] = D[w.Hll + (int64_t)p * 9 + i];
+        Dm[0] += lambda;
+        Dm[4] += lambda;
+        Dm[8] += lambda;
+        const double det = Dm[0] * (Dm[4] * Dm[8] - Dm[5] * Dm[7]) - Dm[1] * (Dm[3] * Dm[8] - Dm[5] * Dm[6]) +
+                           Dm[2] * (Dm[3] * Dm[7] - Dm[4] * Dm[6]);
+        const double id = 1.0 / det;
+        double Iv[9];
+        Iv[0] = (Dm[4] * Dm[8] - Dm[5] * Dm[7]) * id;
+        Iv[1] = (Dm[2] * Dm[7] - Dm[1] * Dm[8]) * id;
+        Iv[2] = (Dm[1] * Dm[5] - Dm[2] * Dm[4]) * id;
+        Iv[3] = (Dm[5] * Dm[6] - Dm[3] * Dm[8]) * id;
+        Iv[4] = (Dm[0] * Dm[8] - Dm[2] * Dm[6]) * id;
+        Iv[5] = (Dm[2] * Dm[3] - Dm[0] * Dm[5]) * id;
+        Iv[6] = (Dm[3] * Dm[7] - Dm[4] * Dm[6]) * id;
+        Iv[7] = (Dm[1] * Dm[6] - Dm[0] * Dm[7]) * id;
+        Iv[8] = (Dm[0] * Dm[4] - Dm[1] * Dm[3]) * id;
+        for (int i = 0; i < 9; i++) D[w.Dinv + (int64_t)p * 9 + i] = Iv[i];
+        const double b0 = D[w.bl + (int64_t)p * 3], b1 = D[w.bl + (int64_t)p * 3 + 1], b2 = D[w.bl + (int64_t)p * 3 + 2];
+        for (int a = 0; a < 3; a++) D[w.tv + (int64_t)p * 3 + a] = Iv[a * 3] * b0 + Iv[a * 3 + 1] * b1 + Iv[a * 3 + 2] * b2;
+    }
+    /* S starts as Hpp + lambda I on its diagonal blocks and zero elsewhere, g as bp: the Schur products are
+       subtracted from them below (disjoint writers, no barrier needed between the two loops) */
+    for (int i = gtid; i < w.nnzb * 36; i += gthreads) {
+        const int bk = i / 36, e = i - bk * 36;
+        const int sl = I[w.blk_rowid + bk];
+        double v = 0.0;
+        if (I[w.blk_col + bk] == sl) {
+            v = D[w.Hpp + (int64_t)sl * 36 + e];
+            if (e % 7 == 0) v += lambda;
+        }
+        D[w.S + i] = v;
+    }
+    for (int i = gtid; i < w.Ncf * 6; i += gthreads) D[w.g + i] = D[w.bp + i];
+}
+/* back-substitution xl = Dinv (bl - sum_e W_e^T x_c) (thread per point) and the trial estimate; returns this thread's
+   share of the gain-ratio denominator */
+__device__ __forceinline__ double ba_phase_backsub(const BAWin &w, double *D, const int32_t *I, bool ok2, double lambda, int gtid, int gthreads) {
+    double scale_loc = 0;
+    for (int p = gtid; p < w.Np; p += gthreads) {
+        double cl[3] = {D[w.bl + (int64_t)p * 3], D[w.bl + (int64_t)p * 3 + 1], D[w.bl + (int64_t)p * 3 + 2]};
+        const int e0 = I[w.pt_start + p], e1 = I[w.pt_start + p + 1];
+        for (int e = e0; e < e1; e++) {
+            const int sl = I[w.slot + I[w.cam + e]];
+            if (sl < 0) continue;
+            const double *We = D + w.W + (int64_t)e * 18;
+            const double *xc = D + w.x + sl * 6;
+            for (int bb = 0; bb < 3; bb++)
+                for (int a = 0; a < 6; a++) cl[bb] -= We[a * 3 + bb] * xc[a];
+        }
+        const double *Iv = D + w.Dinv + (int64_t)p * 9;
+        for (int a = 0; a < 3; a++) {
+            const double v = ok2 ? (Iv[a * 3] * cl[0] + Iv[a * 3 + 1] * cl[1] + Iv[a * 3 + 2] * cl[2]) : 0.0;
+            D[w.pts_t + (int64_t)p * 3 + a] = D[w.pts + (int64_t)p * 3 + a] + v;
+            scale_loc += v * (lambda * v + D[w.bl + (int64_t)p * 3 + a]);
+        }
+    }
+    for (int c = gtid; c < w.Nc; c += gthreads) {
+        const int sl = I[w.slot + c];
+        if (sl >= 0 && ok2) {
+            double u[6];
+            for (int a = 0; a < 6; a++) {
+                u[a] = D[w.x + sl * 6 + a];
+                scale_loc += u[a] * (lambda * u[a] + D[w.bp + (int64_t)sl * 6 + a]);
+            }
+            se3_exp_mul(u, D + w.poses + (int64_t)c * 7, D + w.poses_t + (int64_t)c * 7);
+        } else {
+            for (int a = 0; a < 7; a++) D[w.poses_t + (int64_t)c * 7 + a] = D[w.poses + (int64_t)c * 7 + a];
+        }
+    }
+    return scale_loc;
+}
+/* the second accumulators of the two-part Schur pass start at zero */
+__device__ __forceinline__ void ba_phase_zero2(const BAWin &w, double *D, int gtid, int gthreads) {
+    for (int i = gtid; i < w.nnzb * 36; i += gthreads) D[w.S2 + i] = 0.0;
+    for (int i = gtid; i < w.Ncf * 6; i += gthreads) D[w.g2 + i] = 0.0;
+}
+/* accepted trial: it becomes the estimate */
+__device__ __forceinline__ void ba_phase_accept(const BAWin &w, double *D, int gtid, int gthreads) {
+    for (int i = gtid; i < w.Nc * 7; i += gthreads) D[w.poses + i] = D[w.poses_t + i];
+    for (int i = gtid; i < w.Np * 3; i += gthreads) D[w.pts + i] = D[w.pts_t + i];
+    for (int i = gtid; i < w.E * 2; i += gthreads) D[w.err + i] = D[w.err_t + i];
+}
+
 /* n_iters LM iterations (OptimizationAlgorithmLevenberg::solve) for every window of the batch.  A whole optimize()
  * round runs in ONE launch unless a stop flag has to be polled by the host between iterations: the windows of a batch
  * then advance independently (a window that needs a second LM trial in some iteration does not hold up the other 255,
@@ -1066,130 +1313,17 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
     BA_STAMP(0)
     /* ---- buildSystem: Hll, bl (thread per point; W is written by the camera pass below, which has the same Jacobians
        in hand and stores whole 144-byte records instead of 18 doubles strided over the lanes) ---- */
-    for (int p = gtid; p < w.Np; p += gthreads) {
-        double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
-        const int e0 = I[w.pt_start + p], e1 = I[w.pt_start + p + 1];
-        /* software pipeline over the point's edges: flag, camera id, residual and information of the NEXT edge are
-           fetched while the current one waits for its pose (one dependent round trip per edge instead of three) */
-        uint8_t fn = 0;
-        int cn = 0;
-        double er0n = 0, er1n = 0, infon = 0;
-        if (e0 < e1) {
-            fn = B[w.flags + e0];
-            cn = I[w.cam + e0];
-            er0n = D[w.err + (int64_t)e0 * 2];
-            er1n = D[w.err + (int64_t)e0 * 2 + 1];
-            infon = D[w.info + e0];
-        }
-        for (int e = e0; e < e1; e++) {
-            const uint8_t f = fn;
-            const int c = cn;
-            const double er0 = er0n, er1 = er1n, info = infon;
-            if (e + 1 < e1) {
-                fn = B[w.flags + e + 1];
-                cn = I[w.cam + e + 1];
-                er0n = D[w.err + (int64_t)(e + 1) * 2];
-                er1n = D[w.err + (int64_t)(e + 1) * 2 + 1];
-                infon = D[w.info + e + 1];
-            }
-            if (!(f & 1)) continue;
-            const double *pose = D + w.poses + (int64_t)c * 7;
-            const double *X = D + w.pts + (int64_t)p * 3;
-            double R[9], pc[3];
-            quat_to_R(pose, R);
-            pc[0] = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + pose[4];
-            pc[1] = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + pose[5];
-            pc[2] = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + pose[6];
-            double Ji[6], Jj[12];
-            jacobians(pose, pc, w.fx, w.fy, Ji, Jj);
-            double wgt = info, r0 = -info * er0, r1 = -info * er1;
-            if (f & 2) {
-                const double rw = huber_w((er0 * er0 + er1 * er1) * info, w.delta);
-                wgt *= rw;
-                r0 *= rw;
-                r1 *= rw;
-            }
-            for (int a = 0; a < 3; a++) {
-                b[a] += Ji[a] * r0 + Ji[3 + a] * r1;
-                for (int bb = 0; bb < 3; bb++) H[a * 3 + bb] += wgt * (Ji[a] * Ji[bb] + Ji[3 + a] * Ji[3 + bb]);
-            }
-        }
-        for (int i = 0; i < 9; i++) D[w.Hll + (int64_t)p * 9 + i] = H[i];
-        for (int i = 0; i < 3; i++) D[w.bl + (int64_t)p * 3 + i] = b[i];
-    }
+    ba_phase_hll(w, D, I, B, gtid, gthreads);
     BA_STAMP(1)
     /* ---- Hpp, bp, W = Hpl: one wavefront per free camera, lanes over its edges, shuffle reduction.  (The W record of an
        edge of a FIXED camera is never read: the Schur lists, g and the back-substitution only follow free cameras.) ---- */
-    for (int c = gwave; c < w.Nc; c += gwaves) {
-        const int sl = I[w.slot + c];
-        if (sl < 0) continue;
-        double acc[27];
-        for (int i = 0; i < 27; i++) acc[i] = 0.0;
-        const int k0 = I[w.cam_start + c], k1 = I[w.cam_start + c + 1];
-        const double *pose = D + w.poses + (int64_t)c * 7;
-        for (int k = k0 + lane; k < k1; k += 64) {
-            const int e = I[w.cam_edges + k];
-            const uint8_t f = B[w.flags + e];
-            double2 *We = (double2 *)(D + w.W + (int64_t)e * 18);
-            if (!(f & 1)) { /* switched off: contributes nothing, but its record is read by the block products */
-#pragma unroll
-                for (int i = 0; i < 9; i++) We[i] = double2{0.0, 0.0};
-                continue;
-            }
-            const double *X = D + w.pts + (int64_t)I[w.pt + e] * 3;
-            double R[9], pc[3];
-            quat_to_R(pose, R);
-            pc[0] = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + pose[4];
-            pc[1] = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + pose[5];
-            pc[2] = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + pose[6];
-            double Ji[6], Jj[12];
-            jacobians(pose, pc, w.fx, w.fy, Ji, Jj);
-            const double er0 = D[w.err + (int64_t)e * 2], er1 = D[w.err + (int64_t)e * 2 + 1];
-            const double info = D[w.info + e];
-            double wgt = info, r0 = -info * er0, r1 = -info * er1;
-            if (f & 2) {
-                const double rw = huber_w((er0 * er0 + er1 * er1) * info, w.delta);
-                wgt *= rw;
-                r0 *= rw;
-                r1 *= rw;
-            }
-            int q = 0;
-            for (int a = 0; a < 6; a++)
-                for (int bb = a; bb < 6; bb++) acc[q++] += wgt * (Jj[a] * Jj[bb] + Jj[6 + a] * Jj[6 + bb]);
-            for (int a = 0; a < 6; a++) acc[21 + a] += Jj[a] * r0 + Jj[6 + a] * r1;
-            double wv[18];
-#pragma unroll
-            for (int a = 0; a < 6; a++)
-#pragma unroll
-                for (int bb = 0; bb < 3; bb++) wv[a * 3 + bb] = wgt * (Jj[a] * Ji[bb] + Jj[6 + a] * Ji[3 + bb]);
-#pragma unroll
-            for (int i = 0; i < 9; i++) We[i] = double2{wv[2 * i], wv[2 * i + 1]};
-        }
-        for (int i = 0; i < 27; i++) {
-            double v = acc[i];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            acc[i] = v;
-        }
-        if (lane == 0) {
-            int q = 0;
-            for (int a = 0; a < 6; a++)
-                for (int bb = a; bb < 6; bb++) {
-                    D[w.Hpp + (int64_t)sl * 36 + a * 6 + bb] = acc[q];
-                    D[w.Hpp + (int64_t)sl * 36 + bb * 6 + a] = acc[q];
-                    q++;
-                }
-            for (int a = 0; a < 6; a++) D[w.bp + (int64_t)sl * 6 + a] = acc[21 + a];
-        }
-    }
+    ba_phase_hpp(w, D, I, B, gwave, gwaves, lane);
     team_sync(team, s);
 
     BA_STAMP(2)
     /* ---- computeLambdaInit on the first iteration of an optimize() call ---- */
     if (first_of_round && iter == 0) {
-        double m = 0;
-        for (int i = gtid; i < w.Ncf * 6; i += gthreads) m = fmax(m, fabs(D[w.Hpp + (int64_t)(i / 6) * 36 + (i % 6) * 7]));
-        for (int i = gtid; i < w.Np * 3; i += gthreads) m = fmax(m, fabs(D[w.Hll + (int64_t)(i / 3) * 9 + (i % 3) * 4]));
+        double m = ba_phase_lambda0(w, D, gtid, gthreads);
         m = team_max(m, s, team);
         lambda = 1e-5 * m;
         ni = 2;
@@ -1202,42 +1336,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
         /* ---- Dinv = (Hll + lambda I)^-1 and tv = Dinv bl (thread per point).  Y = W Dinv is never stored: the Schur
            products form it in registers from W and Dinv (54 FMAs per contribution against a 144-byte record written,
            read back ~6 times and mostly missing every cache when 256 windows run at once) ---- */
-        for (int p = gtid; p < w.Np; p += gthreads) {
-            double Dm[9];
-            for (int i = 0; i < 9; i++) Dm[i] = D[w.Hll + (int64_t)p * 9 + i];
-            Dm[0] += lambda;
-            Dm[4] += lambda;
-            Dm[8] += lambda;
-            const double det = Dm[0] * (Dm[4] * Dm[8] - Dm[5] * Dm[7]) - Dm[1] * (Dm[3] * Dm[8] - Dm[5] * Dm[6]) +
-                               Dm[2] * (Dm[3] * Dm[7] - Dm[4] * Dm[6]);
-            const double id = 1.0 / det;
-            double Iv[9];
-            Iv[0] = (Dm[4] * Dm[8] - Dm[5] * Dm[7]) * id;
-            Iv[1] = (Dm[2] * Dm[7] - Dm[1] * Dm[8]) * id;
-            Iv[2] = (Dm[1] * Dm[5] - Dm[2] * Dm[4]) * id;
-            Iv[3] = (Dm[5] * Dm[6] - Dm[3] * Dm[8]) * id;
-            Iv[4] = (Dm[0] * Dm[8] - Dm[2] * Dm[6]) * id;
-            Iv[5] = (Dm[2] * Dm[3] - Dm[0] * Dm[5]) * id;
-            Iv[6] = (Dm[3] * Dm[7] - Dm[4] * Dm[6]) * id;
-            Iv[7] = (Dm[1] * Dm[6] - Dm[0] * Dm[7]) * id;
-            Iv[8] = (Dm[0] * Dm[4] - Dm[1] * Dm[3]) * id;
-            for (int i = 0; i < 9; i++) D[w.Dinv + (int64_t)p * 9 + i] = Iv[i];
-            const double b0 = D[w.bl + (int64_t)p * 3], b1 = D[w.bl + (int64_t)p * 3 + 1], b2 = D[w.bl + (int64_t)p * 3 + 2];
-            for (int a = 0; a < 3; a++) D[w.tv + (int64_t)p * 3 + a] = Iv[a * 3] * b0 + Iv[a * 3 + 1] * b1 + Iv[a * 3 + 2] * b2;
-        }
-        /* S starts as Hpp + lambda I on its diagonal blocks and zero elsewhere, g as bp: the Schur products are
-           subtracted from them below (disjoint writers, no barrier needed between the two loops) */
-        for (int i = gtid; i < w.nnzb * 36; i += gthreads) {
-            const int bk = i / 36, e = i - bk * 36;
-            const int sl = I[w.blk_rowid + bk];
-            double v = 0.0;
-            if (I[w.blk_col + bk] == sl) {
-                v = D[w.Hpp + (int64_t)sl * 36 + e];
-                if (e % 7 == 0) v += lambda;
-            }
-            D[w.S + i] = v;
-        }
-        for (int i = gtid; i < w.Ncf * 6; i += gthreads) D[w.g + i] = D[w.bp + i];
+        ba_phase_dinv(w, D, I, lambda, gtid, gthreads);
         team_sync(team, s);
         BA_STAMP(3)
         if (w.nchunks > 0 && G == 1) {
@@ -1272,7 +1371,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
            PCG otherwise / on request */
         if (use_chol) {
             BA_STAMP(5)
-            ok2 = ba_chol_solve(w, D, I, n, ba_dyn, s, debug);
+            ok2 = ba_chol_solve(w, D, I, n, ba_dyn, &s.bc[0], debug);
             solves++;
             if (debug > 1) { /* residual of the direct solve against the block-sparse S */
                 double r2 = 0, g2 = 0;
@@ -1443,38 +1542,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
         if (G > 1) ok2 = __hip_atomic_load(D + w.xl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0;
         BA_STAMP(7)
         /* ---- back-substitution: xl = Dinv (bl - sum_e W_e^T x_c) (thread per point) + trial update ---- */
-        double scale_loc = 0;
-        for (int p = gtid; p < w.Np; p += gthreads) {
-            double cl[3] = {D[w.bl + (int64_t)p * 3], D[w.bl + (int64_t)p * 3 + 1], D[w.bl + (int64_t)p * 3 + 2]};
-            const int e0 = I[w.pt_start + p], e1 = I[w.pt_start + p + 1];
-            for (int e = e0; e < e1; e++) {
-                const int sl = I[w.slot + I[w.cam + e]];
-                if (sl < 0) continue;
-                const double *We = D + w.W + (int64_t)e * 18;
-                const double *xc = D + w.x + sl * 6;
-                for (int bb = 0; bb < 3; bb++)
-                    for (int a = 0; a < 6; a++) cl[bb] -= We[a * 3 + bb] * xc[a];
-            }
-            const double *Iv = D + w.Dinv + (int64_t)p * 9;
-            for (int a = 0; a < 3; a++) {
-                const double v = ok2 ? (Iv[a * 3] * cl[0] + Iv[a * 3 + 1] * cl[1] + Iv[a * 3 + 2] * cl[2]) : 0.0;
-                D[w.pts_t + (int64_t)p * 3 + a] = D[w.pts + (int64_t)p * 3 + a] + v;
-                scale_loc += v * (lambda * v + D[w.bl + (int64_t)p * 3 + a]);
-            }
-        }
-        for (int c = gtid; c < w.Nc; c += gthreads) {
-            const int sl = I[w.slot + c];
-            if (sl >= 0 && ok2) {
-                double u[6];
-                for (int a = 0; a < 6; a++) {
-                    u[a] = D[w.x + sl * 6 + a];
-                    scale_loc += u[a] * (lambda * u[a] + D[w.bp + (int64_t)sl * 6 + a]);
-                }
-                se3_exp_mul(u, D + w.poses + (int64_t)c * 7, D + w.poses_t + (int64_t)c * 7);
-            } else {
-                for (int a = 0; a < 7; a++) D[w.poses_t + (int64_t)c * 7 + a] = D[w.poses + (int64_t)c * 7 + a];
-            }
-        }
+        const double scale_loc = ba_phase_backsub(w, D, I, ok2, lambda, gtid, gthreads);
         team_sync(team, s);
         BA_STAMP(8)
         double tempChi = eval_chi2_partial(w, D, I, B, w.poses_t, w.pts_t, w.err_t, team);
@@ -1491,9 +1559,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
             ni = 2;
             currentChi = tempChi;
             have_chi = true;
-            for (int i = gtid; i < w.Nc * 7; i += gthreads) D[w.poses + i] = D[w.poses_t + i];
-            for (int i = gtid; i < w.Np * 3; i += gthreads) D[w.pts + i] = D[w.pts_t + i];
-            for (int i = gtid; i < w.E * 2; i += gthreads) D[w.err + i] = D[w.err_t + i];
+            ba_phase_accept(w, D, gtid, gthreads);
         } else {
             lambda *= ni;
             ni *= 2;
@@ -1522,6 +1588,525 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
     if (qmax == 10 || rho == 0) break; /* uniform: terminated */
     if (iter + 1 < n_iters) team_sync(team, s); /* the accepted estimate (written team-strided) is read edge-strided next */
     } /* iterations of this launch */
+}
+
+/* ------------------------------------------------------------------------------------------------------------
+ * The batch path as PHASE KERNELS.  k_ba_iteration keeps a window's whole optimize() round in one launch -- right
+ * for a team working on one window, where a launch per phase would cost more than the phases -- but as ONE kernel
+ * it is compiled for the union of its phases: 256 VGPRs plus 120 spilled, two wavefronts per SIMD, and every phase
+ * runs at that occupancy.  With a few hundred windows in flight the launches are free, so the batch path runs an LM
+ * trial as seven kernels over all windows, each with the registers, LDS and occupancy of its own phase:
+ *     chi2 | Hll | Hpp + W | lambda0, Dinv, S := Hpp + lambda I | Schur | Cholesky | back-substitution, trial, decision
+ * A window's position in g2o's control flow (which iteration, which trial of it, accepted or not) lives in its state
+ * record (ST_PH ...); a workgroup whose window has nothing to do in a phase returns at once.  The host enqueues
+ * n_iters + BA_PH_SPARE trials per round; a window that needed more rejected trials than that is finished by
+ * k_ba_ph_finish, which loops the same phases inside one workgroup until the round is over (so the result never
+ * depends on the number of trials enqueued).  Same arithmetic, same order as the fused kernel with a team of one. */
+struct BARed {
+    double red[BA_W];
+    double bc[8];
+};
+#define BA_PH_SPARE 2
+#define BA_SPLIT_MIN_WINDOWS 129 /* below that the windows get teams (ba_choose_team) */
+
+__global__ void k_ba_ph_round(BABufs bufs, int nwin, int n_iters) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nwin) return;
+    double *st = bufs.D + bufs.wins[i].st;
+    st[ST_PH] = n_iters > 0 ? 0.0 : 2.0;
+    st[ST_BUDGET] = (double)n_iters;
+    st[ST_FIRST] = 1.0;
+    st[ST_HAVECHI] = 0.0;
+    st[ST_QMAX] = 0.0;
+    st[ST_ACCEPT] = 0.0;
+}
+
+/* computeActiveErrors + activeRobustChi2 at the current estimate (skipped when the last trial was accepted: its
+   errors and chi2 are the current ones) */
+template <class SH> __device__ __forceinline__ void ba_ph_chi2(const BAWin &w, double *D, const int32_t *I, const uint8_t *B, SH &s) {
+    double *st = D + w.st;
+    BATeam one;
+    one.G = 1;
+    one.part = 0;
+    const double chi = block_sum(eval_chi2_partial(w, D, I, B, w.poses, w.pts, w.err, one), s);
+    if (threadIdx.x == 0) {
+        st[ST_CHI] = chi;
+        if (st[ST_HAVE_CHI0] == 0.0) {
+            st[ST_CHI0] = chi;
+            st[ST_HAVE_CHI0] = 1.0;
+        }
+    }
+}
+/* computeLambdaInit on the first iteration of a round, then Dinv / tv and the start values of S and g */
+template <class SH> __device__ __forceinline__ void ba_ph_dinv(const BAWin &w, double *D, const int32_t *I, SH &s) {
+    double *st = D + w.st;
+    const bool first = st[ST_FIRST] != 0.0, build = st[ST_PH] == 0.0;
+    double lambda = st[ST_LAMBDA];
+    if (first) lambda = 1e-5 * block_max(ba_phase_lambda0(w, D, threadIdx.x, BA_T), s); /* (its barriers order the reads above before the writes below) */
+    if (threadIdx.x == 0) {
+        if (first) {
+            st[ST_LAMBDA] = lambda;
+            st[ST_NI] = 2.0;
+            st[ST_FIRST] = 0.0;
+        }
+        if (build) st[ST_QMAX] = 0.0;
+    }
+    ba_phase_dinv(w, D, I, lambda, threadIdx.x, BA_T);
+}
+__device__ __forceinline__ void ba_ph_chol(const BAWin &w, double *D, const int32_t *I, double *dyn, double *bad_flag) {
+    double *st = D + w.st;
+    const int n = w.Ncf * 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    ba_chol_assemble<true>(w, D, I, n, threadIdx.x, BA_T, wave, BA_W, [&] { __syncthreads(); });
+    __syncthreads();
+    const bool ok2 = ba_chol_solve<true>(w, D, I, n, dyn, bad_flag, 0);
+    if (threadIdx.x == 0) {
+        st[ST_OK2] = ok2 ? 1.0 : 0.0;
+        st[ST_SOLVES] += 1.0;
+    }
+}
+/* back-substitution and trial estimate, its chi2, the gain ratio and g2o's accept / reject bookkeeping */
+template <class SH> __device__ __forceinline__ void ba_ph_update(const BAWin &w, double *D, const int32_t *I, const uint8_t *B, SH &s) {
+    double *st = D + w.st;
+    double lambda = st[ST_LAMBDA], ni = st[ST_NI];
+    const double currentChi = st[ST_CHI];
+    const bool ok2 = st[ST_OK2] != 0.0;
+    int qmax = (int)st[ST_QMAX], budget = (int)st[ST_BUDGET];
+    double scale = ba_phase_backsub(w, D, I, ok2, lambda, threadIdx.x, BA_T);
+    __syncthreads();
+    BATeam one;
+    one.G = 1;
+    one.part = 0;
+    double tempChi = block_sum(eval_chi2_partial(w, D, I, B, w.poses_t, w.pts_t, w.err_t, one), s);
+    scale = block_sum(scale, s);
+    if (!ok2) tempChi = 1.7976931348623157e308;
+    if (!ok2) scale = 0;
+    scale += 1e-3;
+    const double rho = (currentChi - tempChi) / scale;
+    const bool accept = rho > 0 && isfinite(tempChi);
+    if (accept) {
+        double alpha = 1. - pow((2 * rho - 1), 3);
+        alpha = fmin(alpha, 2. / 3.);
+        lambda *= fmax(1. / 3., alpha);
+        ni = 2;
+        ba_phase_accept(w, D, threadIdx.x, BA_T);
+    } else {
+        lambda *= ni;
+        ni *= 2;
+    }
+    qmax++;
+    if (threadIdx.x == 0) {
+        st[ST_LAMBDA] = lambda;
+        st[ST_NI] = ni;
+        st[ST_QMAX] = (double)qmax;
+        if (accept) {
+            st[ST_CHI] = tempChi;
+            st[ST_HAVECHI] = 1.0;
+        }
+        if (rho < 0 && qmax < 10) {
+            st[ST_PH] = 1.0; /* same iteration, larger lambda */
+        } else {
+            st[ST_ITERS] += 1;
+            if (qmax == 10 || rho == 0) { /* OptimizationAlgorithmLevenberg returns Terminate */
+                st[ST_TERM] = 1.0;
+                st[ST_PH] = 2.0;
+            } else {
+                budget--;
+                st[ST_BUDGET] = (double)budget;
+                st[ST_PH] = budget > 0 ? 0.0 : 2.0;
+            }
+        }
+    }
+}
+
+/* Launch geometry of the phase kernels: grid (window, part).  The streaming phases are strided over the threads of
+ * ALL parts of a window (the phase functions take the thread's index and the stride), so a phase fills the machine
+ * with a few hundred windows however few threads one window can feed; sums over a window are per-part partial sums
+ * (gred) added up in part order by the single-workgroup kernel that needs them: deterministic. */
+#define BA_PH_WINDOW                        \
+    const BAWin &w = bufs.wins[blockIdx.x]; \
+    double *D = bufs.D;                     \
+    const int32_t *I = bufs.I;              \
+    const uint8_t *B = bufs.B;              \
+    const double ph = D[w.st + ST_PH];      \
+    (void)B;                                \
+    (void)I;
+#define BA_PH_T 256 /* threads per workgroup of the streaming phase kernels */
+enum { PH_RED_CHI = 0, PH_RED_SCALE = BA_GMAX, PH_RED_TRIAL = 2 * BA_GMAX }; /* partial-sum rows in gred */
+/* parts that SUM over a window's edges / points: a function of the window alone, so that its arithmetic (the order of
+   its partial sums) does not depend on which other windows share the batch */
+__host__ __device__ __forceinline__ int ba_ph_parts_e(int E) {
+    const int n = (E + 4 * BA_PH_T - 1) / (4 * BA_PH_T);
+    return n < 1 ? 1 : (n > BA_GMAX ? BA_GMAX : n);
+}
+__host__ __device__ __forceinline__ int ba_ph_parts_p(int Np) {
+    const int n = (Np + BA_PH_T - 1) / BA_PH_T;
+    return n < 1 ? 1 : (n > BA_GMAX ? BA_GMAX : n);
+}
+
+template <class SH> __device__ __forceinline__ double block_sum_n(double v, SH &s, int nwaves) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if (lane == 0) s.red[wave] = v;
+    __syncthreads();
+    double t = 0;
+    for (int k = 0; k < nwaves; k++) t += s.red[k];
+    return t;
+}
+/* errors + robust chi2 of this part's edges at (poses, pts): the same two-edges-per-step loop as eval_chi2_partial,
+   for a workgroup of BA_PH_T threads */
+__device__ __forceinline__ double ba_ph_chi2_part(const BAWin &w, double *D, const int32_t *I, const uint8_t *B, int64_t poses, int64_t pts,
+                                                  int64_t err, int gtid, int gthreads) {
+    double acc = 0;
+    for (int e0 = gtid; e0 < w.E; e0 += 2 * gthreads) {
+        const int eA = e0, eB = (e0 + gthreads < w.E) ? e0 + gthreads : e0;
+        const bool vB = e0 + gthreads < w.E;
+        const uint8_t fA = B[w.flags + eA], fB = B[w.flags + eB];
+        const int cA = I[w.cam + eA], cB = I[w.cam + eB], pA = I[w.pt + eA], pB = I[w.pt + eB];
+        const double iA = D[w.info + eA], iB = D[w.info + eB];
+        double erA[2], erB[2], pc[3];
+        project_err(D + poses + (int64_t)cA * 7, D + pts + (int64_t)pA * 3, D + w.obs + (int64_t)eA * 2, w.fx, w.fy, w.cx, w.cy, erA, pc);
+        project_err(D + poses + (int64_t)cB * 7, D + pts + (int64_t)pB * 3, D + w.obs + (int64_t)eB * 2, w.fx, w.fy, w.cx, w.cy, erB, pc);
+        if (fA & 1) {
+            D[err + (int64_t)eA * 2] = erA[0];
+            D[err + (int64_t)eA * 2 + 1] = erA[1];
+            double c = (erA[0] * erA[0] + erA[1] * erA[1]) * iA;
+            if (fA & 2) c = huber_rho0(c, w.delta);
+            acc += c;
+        }
+        if (vB && (fB & 1)) {
+            D[err + (int64_t)eB * 2] = erB[0];
+            D[err + (int64_t)eB * 2 + 1] = erB[1];
+            double c = (erB[0] * erB[0] + erB[1] * erB[1]) * iB;
+            if (fB & 2) c = huber_rho0(c, w.delta);
+            acc += c;
+        }
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(BA_PH_T) void k_ba_ph_chi2(BABufs bufs) {
+    __shared__ BARed s;
+    BA_PH_WINDOW
+    const int parts = ba_ph_parts_e(w.E);
+    if (ph != 0.0 || D[w.st + ST_HAVECHI] != 0.0 || (int)blockIdx.y >= parts) return;
+    const double v = block_sum_n(ba_ph_chi2_part(w, D, I, B, w.poses, w.pts, w.err, blockIdx.y * BA_PH_T + threadIdx.x, parts * BA_PH_T), s, BA_PH_T / 64);
+    if (threadIdx.x == 0) D[w.gred + PH_RED_CHI + blockIdx.y] = v;
+}
+__global__ __launch_bounds__(BA_PH_T) void k_ba_ph_hll(BABufs bufs) {
+    BA_PH_WINDOW
+    if (ph != 0.0) return;
+    ba_phase_hll(w, D, I, B, blockIdx.y * BA_PH_T + threadIdx.x, gridDim.y * BA_PH_T);
+}
+__global__ __launch_bounds__(BA_PH_T) void k_ba_ph_hpp(BABufs bufs) { /* one wavefront per camera */
+    BA_PH_WINDOW
+    if (ph != 0.0) return;
+    ba_phase_hpp(w, D, I, B, blockIdx.y * (BA_PH_T / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), gridDim.y * (BA_PH_T / 64),
+                 threadIdx.x & 63);
+}
+/* single workgroup per window: the current chi2 from its partial sums, computeLambdaInit on the first iteration of a
+   round, trial counter */
+__global__ __launch_bounds__(BA_T) void k_ba_ph_prep(BABufs bufs) {
+    __shared__ BARed s;
+    BA_PH_WINDOW
+    if (ph == 2.0) return;
+    double *st = D + w.st;
+    const bool first = st[ST_FIRST] != 0.0, build = ph == 0.0, need_chi = build && st[ST_HAVECHI] == 0.0;
+    double lambda = 0;
+    if (first) lambda = 1e-5 * block_max(ba_phase_lambda0(w, D, threadIdx.x, BA_T), s);
+    if (threadIdx.x == 0) {
+        if (need_chi) {
+            double chi = 0;
+            for (int g = 0; g < ba_ph_parts_e(w.E); g++) chi += D[w.gred + PH_RED_CHI + g];
+            st[ST_CHI] = chi;
+            if (st[ST_HAVE_CHI0] == 0.0) {
+                st[ST_CHI0] = chi;
+                st[ST_HAVE_CHI0] = 1.0;
+            }
+        }
+        if (first) {
+            st[ST_LAMBDA] = lambda;
+            st[ST_NI] = 2.0;
+            st[ST_FIRST] = 0.0;
+        }
+        if (build) st[ST_QMAX] = 0.0;
+    }
+}
+__global__ __launch_bounds__(BA_PH_T) void k_ba_ph_dinv(BABufs bufs) {
+    BA_PH_WINDOW
+    if (ph == 2.0) return;
+    ba_phase_dinv(w, D, I, D[w.st + ST_LAMBDA], blockIdx.y * BA_PH_T + threadIdx.x, gridDim.y * BA_PH_T);
+    ba_phase_zero2(w, D, blockIdx.y * BA_PH_T + threadIdx.x, gridDim.y * BA_PH_T);
+}
+/* one workgroup per window, all chunks into S / g (diagnostics: ORBSLAM_AMD_BA_SCHUR1) */
+__global__ __launch_bounds__(BA_T) void k_ba_ph_schur(BABufs bufs, int skip) {
+    extern __shared__ __attribute__((aligned(16))) double ba_dyn[];
+    BA_PH_WINDOW
+    if (ph == 2.0) return;
+    ba_schur_chunked(w, D, I, ba_dyn, skip);
+}
+/* The Schur pass of the phase-kernel path: the window's point chunks are split over gridDim.y workgroups of 256
+ * threads, part 0 subtracting its block products from S and g, part 1 from S2 and g2 (zeroed by the Dinv phase; the
+ * Cholesky assembly adds the copies).  Two of these workgroups fit a CU (LDS 78 KB, 4 wavefronts each), so one streams
+ * its next chunk into LDS -- plain loads, written through at once: no registers held across the products, which is
+ * what spilled the single-workgroup version's prefetch -- while the other's lanes are in the block products: the
+ * 9.5 ms of staging per 256-window batch that a lone workgroup per CU spends waiting disappear behind the products.
+ * The products themselves are those of ba_schur_chunked (a full 6 x 6 block per lane, 16 lanes per (block, chunk)
+ * pair, recursive-halving reduction): a row-per-lane mapping with no reduction was built and LOST -- broadcast reads
+ * do not shorten an LDS instruction, so 6 lanes reading 30 doubles each per contribution cost 5x the LDS cycles of
+ * one lane reading 45. */
+#define BA_SH_T 256
+__global__ __launch_bounds__(BA_SH_T) void k_ba_ph_schur2(BABufs bufs, int skip) {
+#pragma clang fp contract(fast)
+    extern __shared__ __attribute__((aligned(16))) double ba_dyn[];
+    BA_PH_WINDOW
+    if (ph == 2.0) return;
+    const int tid = threadIdx.x, part = blockIdx.y;
+    const int ch0 = (int)((int64_t)w.nchunks * part / gridDim.y), ch1 = (int)((int64_t)w.nchunks * (part + 1) / gridDim.y);
+    const int64_t So = part == 0 ? w.S : w.S2, go = part == 0 ? w.g : w.g2;
+    double *sW = ba_dyn, *sD = sW + BA_CHUNK_E * 18, *sT = sD + BA_CHUNK_P * 9;
+    int32_t *sP = (int32_t *)(sT + BA_CHUNK_P * 3);
+    int32_t *sC = sP + BA_CHUNK_E;
+    int32_t *sB = sC + BA_CHUNK_C;
+    int32_t *sBS = sB + BA_CHUNK_B;
+    int32_t *sG = sBS + BA_CHUNK_B + 8;
+    const int grp = tid >> 4, l16 = tid & 15;
+    for (int ch = ch0; ch < ch1; ch++) {
+        const int32_t *cd = I + w.ch_desc + ch * BA_CH_DESC;
+        const int e0 = cd[0], ne = cd[1] - cd[0], p0 = cd[2], npnt = cd[3] - cd[2], cb0 = cd[4], ncb = cd[5] - cd[4];
+        const int cg0 = cd[6], ncg = cd[7] - cd[6], c0 = cd[8], nc = cd[9], g0 = cd[10], ng = cd[11];
+        const double2 *src = (const double2 *)(D + w.W + (int64_t)e0 * 18); /* 144-B records: 16-B aligned */
+        { /* every load of the chunk issued before the first LDS write: ~50 KB in flight per workgroup */
+            constexpr int WPT = (BA_CHUNK_E * 9 + BA_SH_T - 1) / BA_SH_T, DPT = (BA_CHUNK_P * 9 + BA_SH_T - 1) / BA_SH_T,
+                          TPT = (BA_CHUNK_P * 3 + BA_SH_T - 1) / BA_SH_T, EPT = (BA_CHUNK_E + BA_SH_T - 1) / BA_SH_T,
+                          CPT = (BA_CHUNK_C + BA_SH_T - 1) / BA_SH_T, BPT = (BA_CHUNK_B + 1 + BA_SH_T - 1) / BA_SH_T;
+            double2 rW[WPT];
+            double rD[DPT], rT[TPT];
+            int32_t rP[EPT], rG[EPT], rC[CPT], rB[BPT], rBS[BPT];
+#pragma unroll
+            for (int k = 0; k < WPT; k++) rW[k] = tid + k * BA_SH_T < ne * 9 ? src[tid + k * BA_SH_T] : double2{0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < DPT; k++) rD[k] = tid + k * BA_SH_T < npnt * 9 ? D[w.Dinv + (int64_t)p0 * 9 + tid + k * BA_SH_T] : 0.0;
+#pragma unroll
+            for (int k = 0; k < TPT; k++) rT[k] = tid + k * BA_SH_T < npnt * 3 ? D[w.tv + (int64_t)p0 * 3 + tid + k * BA_SH_T] : 0.0;
+#pragma unroll
+            for (int k = 0; k < EPT; k++) {
+                rP[k] = tid + k * BA_SH_T < ne ? I[w.pt + e0 + tid + k * BA_SH_T] - p0 : 0;
+                rG[k] = tid + k * BA_SH_T < ng ? I[w.cg_edge + g0 + tid + k * BA_SH_T] : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < CPT; k++) rC[k] = tid + k * BA_SH_T < nc ? I[w.cb_con + c0 + tid + k * BA_SH_T] : 0;
+#pragma unroll
+            for (int k = 0; k < BPT; k++) {
+                rB[k] = tid + k * BA_SH_T < ncb ? I[w.cb_blk + cb0 + tid + k * BA_SH_T] : 0;
+                rBS[k] = tid + k * BA_SH_T <= ncb ? I[w.cb_start + cb0 + tid + k * BA_SH_T] - c0 : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < WPT; k++)
+                if (tid + k * BA_SH_T < BA_CHUNK_E * 9) ((double2 *)sW)[tid + k * BA_SH_T] = rW[k];
+#pragma unroll
+            for (int k = 0; k < DPT; k++)
+                if (tid + k * BA_SH_T < BA_CHUNK_P * 9) sD[tid + k * BA_SH_T] = rD[k];
+#pragma unroll
+            for (int k = 0; k < TPT; k++)
+                if (tid + k * BA_SH_T < BA_CHUNK_P * 3) sT[tid + k * BA_SH_T] = rT[k];
+#pragma unroll
+            for (int k = 0; k < EPT; k++)
+                if (tid + k * BA_SH_T < BA_CHUNK_E) {
+                    sP[tid + k * BA_SH_T] = rP[k];
+                    sG[tid + k * BA_SH_T] = rG[k];
+                }
+#pragma unroll
+            for (int k = 0; k < CPT; k++)
+                if (tid + k * BA_SH_T < BA_CHUNK_C) sC[tid + k * BA_SH_T] = rC[k];
+#pragma unroll
+            for (int k = 0; k < BPT; k++) {
+                if (tid + k * BA_SH_T < BA_CHUNK_B) sB[tid + k * BA_SH_T] = rB[k];
+                if (tid + k * BA_SH_T <= BA_CHUNK_B) sBS[tid + k * BA_SH_T] = rBS[k];
+            }
+        }
+        __syncthreads();
+        /* blocks: group g takes blocks g, g + 16, ... of the chunk's list (sorted heaviest first on the host) */
+        /* (the block's current value is fetched one pair ahead: a pair's products hide the next pair's round trip) */
+        int u = (skip & 16) ? ncb : grp;
+        double *Sb = D + So + (int64_t)(u < ncb ? sB[u] : 0) * 36 + (l16 < 12 ? l16 : 0) * 3;
+        double sb0 = Sb[0], sb1 = Sb[1], sb2 = Sb[2];
+        for (; u < ncb; u += BA_SH_T / 16) {
+            const int k0 = sBS[u], k1 = sBS[u + 1];
+            const int un = u + BA_SH_T / 16;
+            double *Sn = D + So + (int64_t)(un < ncb ? sB[un] : sB[u]) * 36 + (l16 < 12 ? l16 : 0) * 3;
+            const double sn0 = Sn[0], sn1 = Sn[1], sn2 = Sn[2];
+            double acc[36];
+#pragma unroll
+            for (int i = 0; i < 36; i++) acc[i] = 0.0;
+            for (int k = (skip & 256) ? k1 : k0 + l16; k < k1; k += 16) {
+                const uint32_t ab = (uint32_t)sC[k];
+                const double *Wa = sW + (ab & 511) * 18, *Wb = sW + ((ab >> 9) & 511) * 18, *Iv = sD + (ab >> 18) * 9;
+                double y[18], ww[18];
+#pragma unroll
+                for (int r = 0; r < 6; r++) {
+                    const double w0 = Wa[r * 3], w1 = Wa[r * 3 + 1], w2 = Wa[r * 3 + 2];
+                    y[r * 3] = w0 * Iv[0] + w1 * Iv[3] + w2 * Iv[6];
+                    y[r * 3 + 1] = w0 * Iv[1] + w1 * Iv[4] + w2 * Iv[7];
+                    y[r * 3 + 2] = w0 * Iv[2] + w1 * Iv[5] + w2 * Iv[8];
+                }
+#pragma unroll
+                for (int i = 0; i < 18; i++) ww[i] = Wb[i];
+#pragma unroll
+                for (int r = 0; r < 6; r++)
+#pragma unroll
+                    for (int c = 0; c < 6; c++)
+                        acc[r * 6 + c] += y[r * 3] * ww[c * 3] + y[r * 3 + 1] * ww[c * 3 + 1] + y[r * 3 + 2] * ww[c * 3 + 2];
+            }
+            double d0, d1, d2;
+            group16_reduce36(acc, l16, d0, d1, d2); /* lane q now holds the totals of entries 3q .. 3q+2 */
+            if (l16 < 12) {
+                Sb[0] = sb0 - d0;
+                Sb[1] = sb1 - d1;
+                Sb[2] = sb2 - d2;
+            }
+            Sb = Sn;
+            sb0 = sn0;
+            sb1 = sn1;
+            sb2 = sn2;
+        }
+        /* g: group g takes cameras g, g + 16, ... of the chunk */
+        for (int u = (skip & 64) ? ncg : grp; u < ncg; u += BA_SH_T / 16) {
+            const int sl = I[w.cg_slot + cg0 + u];
+            const int k0 = I[w.cg_start + cg0 + u] - g0, k1 = I[w.cg_start + cg0 + u + 1] - g0;
+            double acc[6] = {0, 0, 0, 0, 0, 0};
+            for (int k = k0 + l16; k < k1; k += 16) {
+                const int a = sG[k];
+                const double *Wa = sW + a * 18, *t = sT + sP[a] * 3;
+                const double t0 = t[0], t1 = t[1], t2 = t[2];
+#pragma unroll
+                for (int r = 0; r < 6; r++) acc[r] += Wa[r * 3] * t0 + Wa[r * 3 + 1] * t1 + Wa[r * 3 + 2] * t2;
+            }
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                double v = acc[r];
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                acc[r] = v;
+            }
+            if (l16 == 0) {
+#pragma unroll
+                for (int r = 0; r < 6; r++) D[go + sl * 6 + r] -= acc[r];
+            }
+        }
+        __syncthreads(); /* the next chunk overwrites the LDS tiles and may touch the same blocks */
+    }
+}
+__global__ __launch_bounds__(BA_T) void k_ba_ph_chol(BABufs bufs) {
+    extern __shared__ __attribute__((aligned(16))) double ba_dyn[];
+    __shared__ double bad_flag[1];
+    BA_PH_WINDOW
+    if (ph == 2.0) return;
+    ba_ph_chol(w, D, I, ba_dyn, bad_flag);
+}
+__global__ __launch_bounds__(BA_PH_T) void k_ba_ph_backsub(BABufs bufs) {
+    __shared__ BARed s;
+    BA_PH_WINDOW
+    const int parts = ba_ph_parts_p(w.Np);
+    if (ph == 2.0 || (int)blockIdx.y >= parts) return;
+    const double v = block_sum_n(ba_phase_backsub(w, D, I, D[w.st + ST_OK2] != 0.0, D[w.st + ST_LAMBDA], blockIdx.y * BA_PH_T + threadIdx.x, parts * BA_PH_T), s, BA_PH_T / 64);
+    if (threadIdx.x == 0) D[w.gred + PH_RED_SCALE + blockIdx.y] = v;
+}
+__global__ __launch_bounds__(BA_PH_T) void k_ba_ph_trial(BABufs bufs) {
+    __shared__ BARed s;
+    BA_PH_WINDOW
+    const int parts = ba_ph_parts_e(w.E);
+    if (ph == 2.0 || (int)blockIdx.y >= parts) return;
+    const double v = block_sum_n(ba_ph_chi2_part(w, D, I, B, w.poses_t, w.pts_t, w.err_t, blockIdx.y * BA_PH_T + threadIdx.x, parts * BA_PH_T), s, BA_PH_T / 64);
+    if (threadIdx.x == 0) D[w.gred + PH_RED_TRIAL + blockIdx.y] = v;
+}
+/* gain ratio and g2o's accept / reject bookkeeping: one thread per window */
+__global__ void k_ba_ph_decide(BABufs bufs, int nwin, int trial_seq) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nwin) return;
+    const BAWin &w = bufs.wins[i];
+    double *D = bufs.D, *st = D + w.st;
+    if (st[ST_PH] == 2.0) return;
+    double lambda = st[ST_LAMBDA], ni = st[ST_NI];
+    const double currentChi = st[ST_CHI];
+    const bool ok2 = st[ST_OK2] != 0.0;
+    int qmax = (int)st[ST_QMAX], budget = (int)st[ST_BUDGET];
+    double tempChi = 0, scale = 0;
+    for (int g = 0; g < ba_ph_parts_e(w.E); g++) tempChi += D[w.gred + PH_RED_TRIAL + g];
+    for (int g = 0; g < ba_ph_parts_p(w.Np); g++) scale += D[w.gred + PH_RED_SCALE + g];
+    if (!ok2) tempChi = 1.7976931348623157e308;
+    if (!ok2) scale = 0;
+    scale += 1e-3;
+    const double rho = (currentChi - tempChi) / scale;
+    const bool accept = rho > 0 && isfinite(tempChi);
+    if (accept) {
+        double alpha = 1. - pow((2 * rho - 1), 3);
+        alpha = fmin(alpha, 2. / 3.);
+        lambda *= fmax(1. / 3., alpha);
+        ni = 2;
+        st[ST_CHI] = tempChi;
+        st[ST_HAVECHI] = 1.0;
+        st[ST_ACCEPT] = (double)(trial_seq + 1); /* k_ba_ph_accept of this trial copies the trial state */
+    } else {
+        lambda *= ni;
+        ni *= 2;
+    }
+    qmax++;
+    st[ST_LAMBDA] = lambda;
+    st[ST_NI] = ni;
+    st[ST_QMAX] = (double)qmax;
+    if (rho < 0 && qmax < 10) {
+        st[ST_PH] = 1.0; /* same iteration, larger lambda */
+    } else {
+        st[ST_ITERS] += 1;
+        if (qmax == 10 || rho == 0) { /* OptimizationAlgorithmLevenberg returns Terminate */
+            st[ST_TERM] = 1.0;
+            st[ST_PH] = 2.0;
+        } else {
+            budget--;
+            st[ST_BUDGET] = (double)budget;
+            st[ST_PH] = budget > 0 ? 0.0 : 2.0;
+        }
+    }
+}
+__global__ __launch_bounds__(BA_PH_T) void k_ba_ph_accept(BABufs bufs, int trial_seq) {
+    const BAWin &w = bufs.wins[blockIdx.x];
+    double *D = bufs.D;
+    if (D[w.st + ST_ACCEPT] != (double)(trial_seq + 1)) return;
+    ba_phase_accept(w, D, blockIdx.y * BA_PH_T + threadIdx.x, gridDim.y * BA_PH_T);
+}
+/* whatever is left of the round, in one workgroup per window (normally nothing: every window is at ST_PH == 2) */
+__global__ __launch_bounds__(BA_T) void k_ba_ph_finish(BABufs bufs) {
+    extern __shared__ __attribute__((aligned(16))) double ba_dyn[];
+    __shared__ BARed s;
+    const BAWin &w = bufs.wins[blockIdx.x];
+    double *D = bufs.D;
+    const int32_t *I = bufs.I;
+    const uint8_t *B = bufs.B;
+    /* EXIT CONDITION: every pass either spends one of the <= 10 trials of an iteration or one iteration of the budget;
+       the pass counter bounds the loop whatever the state record holds */
+    for (int pass = 0; pass < 4096; pass++) {
+        const double ph = D[w.st + ST_PH];
+        if (!(ph == 0.0 || ph == 1.0)) break;
+        if (ph == 0.0) {
+            if (D[w.st + ST_HAVECHI] == 0.0) ba_ph_chi2(w, D, I, B, s);
+            __syncthreads();
+            ba_phase_hll(w, D, I, B, threadIdx.x, BA_T);
+            ba_phase_hpp(w, D, I, B, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), BA_W, threadIdx.x & 63);
+            __syncthreads();
+        }
+        ba_ph_dinv(w, D, I, s);
+        ba_phase_zero2(w, D, threadIdx.x, BA_T);
+        __syncthreads();
+        ba_schur_chunked(w, D, I, ba_dyn, 0);
+        __syncthreads();
+        ba_ph_chol(w, D, I, ba_dyn, &s.bc[0]);
+        __syncthreads();
+        ba_ph_update(w, D, I, B, s);
+        __syncthreads();
+    }
 }
 
 /* between rounds: re-evaluate every edge at the accepted estimate, switch off edges with chi2 above
@@ -1583,7 +2168,8 @@ static int64_t BAWin::*const kIntFields[] = {&BAWin::cam,     &BAWin::pt,      &
 static int64_t BAWin::*const kScratchFields[] = {&BAWin::poses_t, &BAWin::pts_t, &BAWin::err, &BAWin::err_t, &BAWin::W,
                                                  &BAWin::tv,      &BAWin::Hpp,   &BAWin::bp,  &BAWin::Hll,   &BAWin::bl,
                                                  &BAWin::Dinv,    &BAWin::S,     &BAWin::g,   &BAWin::Minv,  &BAWin::x,
-                                                 &BAWin::xl,      &BAWin::A,     &BAWin::Linv, &BAWin::gred,  &BAWin::pcgv};
+                                                 &BAWin::xl,      &BAWin::A,     &BAWin::Linv, &BAWin::gred,  &BAWin::pcgv,
+                                                 &BAWin::S2,      &BAWin::g2};
 #define BA_CHOL_LDS_BYTES (128 * 1024) /* dynamic LDS the blocked Cholesky may take beside the static 25 KB */
 
 /* Lay one problem out in the host staging vectors; returns an error code.  `team`: the window will be spread over
@@ -1733,7 +2319,7 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hO, std::vecto
             }
             /* (p1 > p0: a single point never exceeds BA_CHUNK_E edges here; one with more than BA_CHUNK_C contributions
                or BA_CHUNK_B blocks sends the window to the list path below) */
-            const int e0 = cnt[p0], e1 = cnt[p1], chid = (int)chd.size() / 12;
+            const int e0 = cnt[p0], e1 = cnt[p1], chid = (int)chd.size() / BA_CH_DESC;
             /* pass 1: which blocks / cameras does the chunk touch, and how many contributions each */
             tmp_blk.clear();
             tmp_slot.clear();
@@ -1798,12 +2384,12 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hO, std::vecto
                     for (int b = cnt[pt]; b < cnt[pt + 1]; b++) {
                         const int s2 = eslot[b];
                         if (s2 < s1) continue;
-                        cbc[cbp[blk_pos[row[s2]]]++] = (a - e0) | ((b - e0) << 16);
+                        cbc[cbp[blk_pos[row[s2]]]++] = (a - e0) | ((b - e0) << 9) | ((pt - p0) << 18);
                     }
                 }
-            const int d[12] = {e0, e1, p0, p1, cb0, (int)cbb.size(), cg0, (int)cgs.size(),
-                               cbs[cb0], cbs.back() - cbs[cb0], cgst[cg0], cgst.back() - cgst[cg0]};
-            chd.insert(chd.end(), d, d + 12);
+            const int d[BA_CH_DESC] = {e0, e1, p0, p1, cb0, (int)cbb.size(), cg0, (int)cgs.size(),
+                                       cbs[cb0], cbs.back() - cbs[cb0], cgst[cg0], cgst.back() - cgst[cg0], 0, 0, 0, 0};
+            chd.insert(chd.end(), d, d + BA_CH_DESC);
             p0 = p1;
         }
         if (chunk_overflow) return stage_problem(p, hO, hD, scratchD, hI, hB, hw, true); /* nothing laid out yet */
@@ -1851,6 +2437,8 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hO, std::vecto
     w.Dinv = allocS((size_t)Np * 9);
     w.S = allocS((size_t)nnzb * 36);
     w.g = allocS((size_t)Ncf * 6);
+    w.S2 = chunked ? allocS((size_t)nnzb * 36) : w.S; /* (never read when the window is not chunked) */
+    w.g2 = chunked ? allocS((size_t)Ncf * 6) : w.g;
     w.Minv = allocS((size_t)Ncf * 36);
     w.x = allocS((size_t)Ncf * 6);
     w.xl = allocS(2);
@@ -1938,7 +2526,7 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hO, std::vecto
     w.con_start = putI(ccount);
     w.con_e1 = putI(ce1);
     w.con_e2 = putI(ce2);
-    w.nchunks = (int)chd.size() / 12;
+    w.nchunks = (int)chd.size() / BA_CH_DESC;
     w.ch_desc = putI(chd);
     w.cb_blk = putI(cbb);
     w.cb_start = putI(cbs);
@@ -1977,6 +2565,7 @@ struct BAJob {
     std::vector<hipEvent_t> prof_ev; /* pairs around every k_ba_iteration launch (profiling only) */
     int prof_launches = 0;
     int team = 1;
+    bool split = false; /* ran as phase kernels (k_ba_ph_*) */
     double t_start = 0, t_staged = 0, t_enqueued = 0;
 };
 
@@ -2278,7 +2867,112 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
     J.prof_launches = 0;
     int seq = 0;
     bool halted = false;
-    for (int round = 0; round < P0.n_rounds && !halted; round++) {
+    /* the phase-kernel path: a batch of whole workgroups per window, every window on the chunked Schur pass and the
+       dense Cholesky, nobody polling a stop flag, no in-kernel timers asked for.  ORBSLAM_AMD_BA_SPLIT=0 / 1 forces
+       the fused kernel / the phase kernels (when eligible) whatever the batch size. */
+    bool split = G == 1 && s->solver == 1 && !any_stop_ptr && debug == 0;
+    size_t chol_doubles = 0;
+    for (int i = 0; i < nwin && split; i++) {
+        const BAWin &w = J.wins[i];
+        const size_t need = (size_t)std::max(w.ch_pm, 0) * CH_LD + 2 * 16 * CH_LD + (((size_t)w.Ncf * 6 + 15) & ~(size_t)15);
+        if (w.nchunks <= 0 || w.ch_pm <= 0 || w.Ncf <= 0 || need > (size_t)dyn_doubles) split = false;
+        chol_doubles = std::max(chol_doubles, need);
+    }
+    {
+        static const char *force = getenv("ORBSLAM_AMD_BA_SPLIT");
+        if (force && force[0] == '0') split = false;
+        if (!(force && force[0] == '1') && nwin < BA_SPLIT_MIN_WINDOWS) split = false;
+    }
+    J.split = split;
+    if (split) {
+        static PerDeviceLdsLimit lim_schur, lim_chol, lim_fin;
+        static const int schur_skip = getenv("ORBSLAM_AMD_BA_SCHUR_SKIP") ? atoi(getenv("ORBSLAM_AMD_BA_SCHUR_SKIP")) : 0; /* timing experiments (results invalid) */
+        static PerDeviceLdsLimit lim_schur2;
+        static const bool schur1 = getenv("ORBSLAM_AMD_BA_SCHUR1") != nullptr; /* diagnostics: one workgroup per window */
+        BCHK(lim_schur.ensure((const void *)k_ba_ph_schur, (size_t)BA_CHUNK_DOUBLES * 8));
+        BCHK(lim_schur2.ensure((const void *)k_ba_ph_schur2, (size_t)BA_CHUNK_DOUBLES * 8));
+        BCHK(lim_chol.ensure((const void *)k_ba_ph_chol, chol_doubles * 8));
+        BCHK(lim_fin.ensure((const void *)k_ba_ph_finish, (size_t)dyn_doubles * 8));
+        static const bool phase_prof = getenv("ORBSLAM_AMD_BA_PHASE_PROF") != nullptr; /* diagnostics: serialises the phases */
+        double phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        hipEvent_t pe0 = nullptr, pe1 = nullptr;
+        if (phase_prof) {
+            BCHK(hipEventCreate(&pe0));
+            BCHK(hipEventCreate(&pe1));
+        }
+        auto timed = [&](int slot, auto &&launch) -> int {
+            if (phase_prof) BCHK(hipEventRecord(pe0, s->stream));
+            launch();
+            BCHK(hipGetLastError());
+            if (phase_prof) {
+                BCHK(hipEventRecord(pe1, s->stream));
+                BCHK(hipEventSynchronize(pe1));
+                float ms = 0;
+                BCHK(hipEventElapsedTime(&ms, pe0, pe1));
+                phase_ms[slot] += ms;
+            }
+            return ORB_OK;
+        };
+        /* parts per window of the streaming phases: enough workgroups of BA_PH_T threads for the largest window, capped
+           so that a batch of a few hundred windows is a few thousand workgroups */
+        int maxE = 0, maxP = 0, maxC = 0;
+        for (int i = 0; i < nwin; i++) {
+            maxE = std::max(maxE, J.wins[i].E);
+            maxP = std::max(maxP, J.wins[i].Np);
+            maxC = std::max(maxC, J.wins[i].Nc);
+        }
+        const int partsE = ba_ph_parts_e(maxE), partsP = ba_ph_parts_p(maxP);
+        const int partsC = std::max(1, (maxC + BA_PH_T / 64 - 1) / (BA_PH_T / 64));
+        int trial_seq = 0;
+        for (int round = 0; round < P0.n_rounds; round++) {
+            const int nit = P0.rounds[round];
+            if (s->profiling) BCHK(hipEventRecord(J.prof_ev[2 * J.prof_launches], s->stream));
+            hipLaunchKernelGGL(k_ba_ph_round, dim3((nwin + 63) / 64), dim3(64), 0, s->stream, bufs, nwin, nit);
+            BCHK(hipGetLastError());
+            const int trials = nit > 0 ? nit + BA_PH_SPARE : 0;
+            for (int t = 0; t < trials; t++, trial_seq++) {
+                const dim3 gE(nwin, partsE), gP(nwin, partsP), gC(nwin, partsC), tb(BA_PH_T);
+                if ((rc = timed(0, [&] { hipLaunchKernelGGL(k_ba_ph_chi2, gE, tb, 0, s->stream, bufs); }))) return rc;
+                if ((rc = timed(1, [&] { hipLaunchKernelGGL(k_ba_ph_hll, gP, tb, 0, s->stream, bufs); }))) return rc;
+                if ((rc = timed(2, [&] { hipLaunchKernelGGL(k_ba_ph_hpp, gC, tb, 0, s->stream, bufs); }))) return rc;
+                if ((rc = timed(3, [&] {
+                         hipLaunchKernelGGL(k_ba_ph_prep, dim3(nwin), dim3(BA_T), 0, s->stream, bufs);
+                         hipLaunchKernelGGL(k_ba_ph_dinv, gP, tb, 0, s->stream, bufs);
+                     })))
+                    return rc;
+                if ((rc = timed(4, [&] {
+                         if (schur1)
+                             hipLaunchKernelGGL(k_ba_ph_schur, dim3(nwin), dim3(BA_T), (size_t)BA_CHUNK_DOUBLES * 8, s->stream, bufs, schur_skip);
+                         else
+                             hipLaunchKernelGGL(k_ba_ph_schur2, dim3(nwin, 2), dim3(BA_SH_T), (size_t)BA_CHUNK_DOUBLES * 8, s->stream, bufs, schur_skip);
+                     })))
+                    return rc;
+                if ((rc = timed(5, [&] { hipLaunchKernelGGL(k_ba_ph_chol, dim3(nwin), dim3(BA_T), chol_doubles * 8, s->stream, bufs); }))) return rc;
+                if ((rc = timed(6, [&] {
+                         hipLaunchKernelGGL(k_ba_ph_backsub, gP, tb, 0, s->stream, bufs);
+                         hipLaunchKernelGGL(k_ba_ph_trial, gE, tb, 0, s->stream, bufs);
+                         hipLaunchKernelGGL(k_ba_ph_decide, dim3((nwin + 63) / 64), dim3(64), 0, s->stream, bufs, nwin, trial_seq);
+                         hipLaunchKernelGGL(k_ba_ph_accept, gE, tb, 0, s->stream, bufs, trial_seq);
+                     })))
+                    return rc;
+            }
+            if (nit > 0)
+                if ((rc = timed(7, [&] { hipLaunchKernelGGL(k_ba_ph_finish, dim3(nwin), dim3(BA_T), (size_t)dyn_doubles * 8, s->stream, bufs); }))) return rc;
+            if (s->profiling) BCHK(hipEventRecord(J.prof_ev[2 * J.prof_launches + 1], s->stream));
+            J.prof_launches++;
+            if (round + 1 < P0.n_rounds) {
+                hipLaunchKernelGGL(k_ba_classify, dim3(nwin), dim3(BA_T), 0, s->stream, bufs, P0.drop_robust_after == round ? 1 : 0, 0);
+                BCHK(hipGetLastError());
+            }
+        }
+        if (phase_prof) {
+            fprintf(stderr, "[ba] phase kernels, %d windows, ms: chi2 %.2f | Hll %.2f | Hpp+W %.2f | Dinv %.2f | Schur %.2f | Cholesky %.2f | update+trial %.2f | finish %.2f\n",
+                    nwin, phase_ms[0], phase_ms[1], phase_ms[2], phase_ms[3], phase_ms[4], phase_ms[5], phase_ms[6], phase_ms[7]);
+            hipEventDestroy(pe0);
+            hipEventDestroy(pe1);
+        }
+    }
+    for (int round = 0; round < P0.n_rounds && !halted && !split; round++) {
         /* one launch per optimize() round; per iteration only when the host has a stop flag to poll in between */
         const int per_launch = any_stop_ptr ? 1 : std::max(P0.rounds[round], 1);
         for (int it = 0; it < P0.rounds[round]; it += per_launch) {
@@ -2388,6 +3082,7 @@ static int ba_finish(BASolver *s, BAJob &J) {
                 J.pD[J.wins[0].st + ST_T0 + 16] * 1e-5, J.pD[J.wins[0].st + ST_T0 + 17] * 1e-5, J.pD[J.wins[0].st + ST_T0 + 18] * 1e-5,
                 J.pD[J.wins[0].st + ST_T0 + 19] * 1e-5, J.pD[J.wins[0].st + ST_T0 + 20] * 1e-5, J.pD[J.wins[0].st + ST_T0 + 21] * 1e-5,
                 J.pD[J.wins[0].st + ST_T0 + 22] * 1e-5);
+        fprintf(stderr, "[ba] diag tile ms: load %.2f columns %.2f inverse %.2f\n", J.pD[J.wins[0].st + ST_T0 + 17] * 1e-5, J.pD[J.wins[0].st + ST_T0 + 14] * 1e-5, J.pD[J.wins[0].st + ST_T0 + 15] * 1e-5);
     }
     return ORB_OK;
 }
