@@ -71,6 +71,7 @@ struct BAWin {
     /* doubles */
     int64_t poses, poses_t, pts, pts_t, obs, info, err, err_t, W, tv, Hpp, bp, Hll, bl, Dinv, S, g, Minv, x, xl, st;
     int64_t A, Linv; /* dense reduced system (np x np) and inverse diagonal blocks of its Cholesky factor */
+    int64_t Rc;      /* rotation matrices of the cameras (9 doubles each), written by the camera pass of the phase-kernel path */
     int64_t S2, g2;  /* second accumulator of the Schur products and of g (phase-kernel path: the window's chunks are split
                         over two workgroups; the Cholesky assembly adds S and S2, g and g2); chunked windows only */
     /* ints */
@@ -241,6 +242,36 @@ __device__ __forceinline__ void jacobians(const double *pose, const double pc[3]
     Jj[9] = 0;
     Jj[10] = -1. / z * fy;
     Jj[11] = y / z_2 * fy;
+}
+
+/* The phase-kernel batch path does not store W = Hpl (18 doubles per edge, written once and read twice per LM trial:
+ * with 256 windows in flight that is three quarters of the solver's HBM traffic).  It stores what W is a function of
+ * besides the camera's rotation: x/z, y/z, 1/z of the point in the camera frame and the edge's (robustified) weight --
+ * 32 bytes -- and every consumer rebuilds the 6 x 3 block from the record and R (no division, ~110 flops). */
+__device__ __forceinline__ void ba_w_from_record(const double rec[4], const double *R, double fx, double fy, double W[18]) {
+    const double xz = rec[0], yz = rec[1], iz = rec[2], wgt = rec[3];
+    double Ji[6], Jj[12];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        Ji[c] = -iz * (fx * R[c] - xz * fx * R[6 + c]);
+        Ji[3 + c] = -iz * (fy * R[3 + c] - yz * fy * R[6 + c]);
+    }
+    Jj[0] = xz * yz * fx;
+    Jj[1] = -(1 + xz * xz) * fx;
+    Jj[2] = yz * fx;
+    Jj[3] = -iz * fx;
+    Jj[4] = 0;
+    Jj[5] = xz * iz * fx;
+    Jj[6] = (1 + yz * yz) * fy;
+    Jj[7] = -xz * yz * fy;
+    Jj[8] = -xz * fy;
+    Jj[9] = 0;
+    Jj[10] = -iz * fy;
+    Jj[11] = yz * iz * fy;
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) W[a * 3 + b] = wgt * (Jj[a] * Ji[b] + Jj[6 + a] * Ji[3 + b]);
 }
 
 struct BAShared {
@@ -1087,6 +1118,7 @@ __device__ __forceinline__ void ba_phase_hll(const BAWin &w, double *D, const in
 }
 /* Hpp, bp, W = Hpl: one wavefront per free camera, lanes over its edges, shuffle reduction.  (The W record of an edge of a
    FIXED camera is never read: the Schur lists, g and the back-substitution only follow free cameras.) */
+template <bool COMPACT = false>
 __device__ __forceinline__ void ba_phase_hpp(const BAWin &w, double *D, const int32_t *I, const uint8_t *B, int gwave, int gwaves, int lane) {
     for (int c = gwave; c < w.Nc; c += gwaves) {
         const int sl = I[w.slot + c];
@@ -1095,13 +1127,21 @@ __device__ __forceinline__ void ba_phase_hpp(const BAWin &w, double *D, const in
         for (int i = 0; i < 27; i++) acc[i] = 0.0;
         const int k0 = I[w.cam_start + c], k1 = I[w.cam_start + c + 1];
         const double *pose = D + w.poses + (int64_t)c * 7;
+        if (COMPACT && lane < 9) { /* the camera's rotation, for the consumers of the W records */
+            double Rm[9];
+            quat_to_R(pose, Rm);
+            double v = Rm[0];
+#pragma unroll
+            for (int i = 1; i < 9; i++) v = lane == i ? Rm[i] : v;
+            D[w.Rc + (int64_t)c * 9 + lane] = v;
+        }
         for (int k = k0 + lane; k < k1; k += 64) {
             const int e = I[w.cam_edges + k];
             const uint8_t f = B[w.flags + e];
-            double2 *We = (double2 *)(D + w.W + (int64_t)e * 18);
+            double2 *We = (double2 *)(D + w.W + (int64_t)e * (COMPACT ? 4 : 18));
             if (!(f & 1)) { /* switched off: contributes nothing, but its record is read by the block products */
-    #pragma unroll
-                for (int i = 0; i < 9; i++) We[i] = double2{0.0, 0.0};
+#pragma unroll
+                for (int i = 0; i < (COMPACT ? 2 : 9); i++) We[i] = double2{0.0, 0.0};
                 continue;
             }
             const double *X = D + w.pts + (int64_t)I[w.pt + e] * 3;
@@ -1125,17 +1165,23 @@ __device__ __forceinline__ void ba_phase_hpp(const BAWin &w, double *D, const in
             for (int a = 0; a < 6; a++)
                 for (int bb = a; bb < 6; bb++) acc[q++] += wgt * (Jj[a] * Jj[bb] + Jj[6 + a] * Jj[6 + bb]);
             for (int a = 0; a < 6; a++) acc[21 + a] += Jj[a] * r0 + Jj[6 + a] * r1;
-            double wv[18];
-    #pragma unroll
-            for (int a = 0; a < 6; a++)
-    #pragma unroll
-                for (int bb = 0; bb < 3; bb++) wv[a * 3 + bb] = wgt * (Jj[a] * Ji[bb] + Jj[6 + a] * Ji[3 + bb]);
-    #pragma unroll
-            for (int i = 0; i < 9; i++) We[i] = double2{wv[2 * i], wv[2 * i + 1]};
+            if (COMPACT) {
+                const double iz = 1.0 / pc[2];
+                We[0] = double2{pc[0] * iz, pc[1] * iz};
+                We[1] = double2{iz, wgt};
+            } else {
+                double wv[18];
+#pragma unroll
+                for (int a = 0; a < 6; a++)
+#pragma unroll
+                    for (int bb = 0; bb < 3; bb++) wv[a * 3 + bb] = wgt * (Jj[a] * Ji[bb] + Jj[6 + a] * Ji[3 + bb]);
+#pragma unroll
+                for (int i = 0; i < 9; i++) We[i] = double2{wv[2 * i], wv[2 * i + 1]};
+            }
         }
         for (int i = 0; i < 27; i++) {
             double v = acc[i];
-    #pragma unroll
+#pragma unroll
             for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
             acc[i] = v;
         }
@@ -1201,18 +1247,29 @@ __device__ __forceinline__ void ba_phase_dinv(const BAWin &w, double *D, const i
 }
 /* back-substitution xl = Dinv (bl - sum_e W_e^T x_c) (thread per point) and the trial estimate; returns this thread's
    share of the gain-ratio denominator */
+template <bool COMPACT = false>
 __device__ __forceinline__ double ba_phase_backsub(const BAWin &w, double *D, const int32_t *I, bool ok2, double lambda, int gtid, int gthreads) {
     double scale_loc = 0;
     for (int p = gtid; p < w.Np; p += gthreads) {
         double cl[3] = {D[w.bl + (int64_t)p * 3], D[w.bl + (int64_t)p * 3 + 1], D[w.bl + (int64_t)p * 3 + 2]};
         const int e0 = I[w.pt_start + p], e1 = I[w.pt_start + p + 1];
         for (int e = e0; e < e1; e++) {
-            const int sl = I[w.slot + I[w.cam + e]];
+            const int c = I[w.cam + e], sl = I[w.slot + c];
             if (sl < 0) continue;
-            const double *We = D + w.W + (int64_t)e * 18;
             const double *xc = D + w.x + sl * 6;
-            for (int bb = 0; bb < 3; bb++)
-                for (int a = 0; a < 6; a++) cl[bb] -= We[a * 3 + bb] * xc[a];
+            if (COMPACT) {
+                const double2 *rc = (const double2 *)(D + w.W + (int64_t)e * 4);
+                const double2 r0 = rc[0], r1 = rc[1];
+                const double rec[4] = {r0.x, r0.y, r1.x, r1.y};
+                double Wr[18];
+                ba_w_from_record(rec, D + w.Rc + (int64_t)c * 9, w.fx, w.fy, Wr);
+                for (int bb = 0; bb < 3; bb++)
+                    for (int a = 0; a < 6; a++) cl[bb] -= Wr[a * 3 + bb] * xc[a];
+            } else {
+                const double *We = D + w.W + (int64_t)e * 18;
+                for (int bb = 0; bb < 3; bb++)
+                    for (int a = 0; a < 6; a++) cl[bb] -= We[a * 3 + bb] * xc[a];
+            }
         }
         const double *Iv = D + w.Dinv + (int64_t)p * 9;
         for (int a = 0; a < 3; a++) {
@@ -1672,7 +1729,7 @@ template <class SH> __device__ __forceinline__ void ba_ph_update(const BAWin &w,
     const double currentChi = st[ST_CHI];
     const bool ok2 = st[ST_OK2] != 0.0;
     int qmax = (int)st[ST_QMAX], budget = (int)st[ST_BUDGET];
-    double scale = ba_phase_backsub(w, D, I, ok2, lambda, threadIdx.x, BA_T);
+    double scale = ba_phase_backsub<true>(w, D, I, ok2, lambda, threadIdx.x, BA_T);
     __syncthreads();
     BATeam one;
     one.G = 1;
@@ -1803,7 +1860,7 @@ __global__ __launch_bounds__(BA_PH_T) void k_ba_ph_hll(BABufs bufs) {
 __global__ __launch_bounds__(BA_PH_T) void k_ba_ph_hpp(BABufs bufs) { /* one wavefront per camera */
     BA_PH_WINDOW
     if (ph != 0.0) return;
-    ba_phase_hpp(w, D, I, B, blockIdx.y * (BA_PH_T / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), gridDim.y * (BA_PH_T / 64),
+    ba_phase_hpp<true>(w, D, I, B, blockIdx.y * (BA_PH_T / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), gridDim.y * (BA_PH_T / 64),
                  threadIdx.x & 63);
 }
 /* single workgroup per window: the current chi2 from its partial sums, computeLambdaInit on the first iteration of a
@@ -1840,62 +1897,59 @@ __global__ __launch_bounds__(BA_PH_T) void k_ba_ph_dinv(BABufs bufs) {
     ba_phase_dinv(w, D, I, D[w.st + ST_LAMBDA], blockIdx.y * BA_PH_T + threadIdx.x, gridDim.y * BA_PH_T);
     ba_phase_zero2(w, D, blockIdx.y * BA_PH_T + threadIdx.x, gridDim.y * BA_PH_T);
 }
-/* one workgroup per window, all chunks into S / g (diagnostics: ORBSLAM_AMD_BA_SCHUR1) */
-__global__ __launch_bounds__(BA_T) void k_ba_ph_schur(BABufs bufs, int skip) {
-    extern __shared__ __attribute__((aligned(16))) double ba_dyn[];
-    BA_PH_WINDOW
-    if (ph == 2.0) return;
-    ba_schur_chunked(w, D, I, ba_dyn, skip);
-}
-/* The Schur pass of the phase-kernel path: the window's point chunks are split over gridDim.y workgroups of 256
- * threads, part 0 subtracting its block products from S and g, part 1 from S2 and g2 (zeroed by the Dinv phase; the
- * Cholesky assembly adds the copies).  Two of these workgroups fit a CU (LDS 78 KB, 4 wavefronts each), so one streams
- * its next chunk into LDS -- plain loads, written through at once: no registers held across the products, which is
- * what spilled the single-workgroup version's prefetch -- while the other's lanes are in the block products: the
- * 9.5 ms of staging per 256-window batch that a lone workgroup per CU spends waiting disappear behind the products.
+/* The Schur pass of the phase-kernel path: the window's point chunks are split over two groups of 256 threads,
+ * part 0 subtracting its block products from S and g, part 1 from S2 and g2 (zeroed by the Dinv phase; the Cholesky
+ * assembly adds the copies).  k_ba_ph_schur2 runs the parts as workgroups: two of them fit a CU (LDS 78 KB, 4
+ * wavefronts each), so one streams its next chunk into LDS -- every load of the chunk in flight at once, written
+ * through as it lands: no registers held across the products, which is what spilled the single-workgroup version's
+ * prefetch -- while the other's lanes are in the block products.  The W tile is REBUILT from the 32-byte edge
+ * records (ba_w_from_record): the pass reads 0.3 GB per 256 windows instead of 1.3.
  * The products themselves are those of ba_schur_chunked (a full 6 x 6 block per lane, 16 lanes per (block, chunk)
  * pair, recursive-halving reduction): a row-per-lane mapping with no reduction was built and LOST -- broadcast reads
  * do not shorten an LDS instruction, so 6 lanes reading 30 doubles each per contribution cost 5x the LDS cycles of
- * one lane reading 45. */
+ * one lane reading 45.
+ * `tid` is the thread's index inside its part, `nloop` the (uniform) number of chunk steps every part of the
+ * workgroup goes through -- k_ba_ph_finish runs both parts inside one 512-thread workgroup and they share its barriers. */
 #define BA_SH_T 256
-__global__ __launch_bounds__(BA_SH_T) void k_ba_ph_schur2(BABufs bufs, int skip) {
+__device__ __forceinline__ void ba_schur_part(const BAWin &w, double *D, const int32_t *I, double *tile, int tid, int part, int nparts,
+                                              int nloop, int skip) {
 #pragma clang fp contract(fast)
-    extern __shared__ __attribute__((aligned(16))) double ba_dyn[];
-    BA_PH_WINDOW
-    if (ph == 2.0) return;
-    const int tid = threadIdx.x, part = blockIdx.y;
-    const int ch0 = (int)((int64_t)w.nchunks * part / gridDim.y), ch1 = (int)((int64_t)w.nchunks * (part + 1) / gridDim.y);
+    const int ch0 = (int)((int64_t)w.nchunks * part / nparts), ch1 = (int)((int64_t)w.nchunks * (part + 1) / nparts);
     const int64_t So = part == 0 ? w.S : w.S2, go = part == 0 ? w.g : w.g2;
-    double *sW = ba_dyn, *sD = sW + BA_CHUNK_E * 18, *sT = sD + BA_CHUNK_P * 9;
+    double *sW = tile, *sD = sW + BA_CHUNK_E * 18, *sT = sD + BA_CHUNK_P * 9;
     int32_t *sP = (int32_t *)(sT + BA_CHUNK_P * 3);
     int32_t *sC = sP + BA_CHUNK_E;
     int32_t *sB = sC + BA_CHUNK_C;
     int32_t *sBS = sB + BA_CHUNK_B;
     int32_t *sG = sBS + BA_CHUNK_B + 8;
     const int grp = tid >> 4, l16 = tid & 15;
-    for (int ch = ch0; ch < ch1; ch++) {
-        const int32_t *cd = I + w.ch_desc + ch * BA_CH_DESC;
-        const int e0 = cd[0], ne = cd[1] - cd[0], p0 = cd[2], npnt = cd[3] - cd[2], cb0 = cd[4], ncb = cd[5] - cd[4];
-        const int cg0 = cd[6], ncg = cd[7] - cd[6], c0 = cd[8], nc = cd[9], g0 = cd[10], ng = cd[11];
-        const double2 *src = (const double2 *)(D + w.W + (int64_t)e0 * 18); /* 144-B records: 16-B aligned */
-        { /* every load of the chunk issued before the first LDS write: ~50 KB in flight per workgroup */
-            constexpr int WPT = (BA_CHUNK_E * 9 + BA_SH_T - 1) / BA_SH_T, DPT = (BA_CHUNK_P * 9 + BA_SH_T - 1) / BA_SH_T,
-                          TPT = (BA_CHUNK_P * 3 + BA_SH_T - 1) / BA_SH_T, EPT = (BA_CHUNK_E + BA_SH_T - 1) / BA_SH_T,
-                          CPT = (BA_CHUNK_C + BA_SH_T - 1) / BA_SH_T, BPT = (BA_CHUNK_B + 1 + BA_SH_T - 1) / BA_SH_T;
-            double2 rW[WPT];
+    for (int it = 0; it < nloop; it++) {
+        const int ch = ch0 + it;
+        const bool live = ch < ch1;
+        const int32_t *cd = I + w.ch_desc + (live ? ch : ch0) * BA_CH_DESC;
+        const int e0 = cd[0], ne = live ? cd[1] - cd[0] : 0, p0 = cd[2], npnt = live ? cd[3] - cd[2] : 0, cb0 = cd[4], ncb = live ? cd[5] - cd[4] : 0;
+        const int cg0 = cd[6], ncg = live ? cd[7] - cd[6] : 0, c0 = cd[8], nc = live ? cd[9] : 0, g0 = cd[10], ng = live ? cd[11] : 0;
+        { /* every load of the chunk issued before the first LDS write */
+            constexpr int DPT = (BA_CHUNK_P * 9 + BA_SH_T - 1) / BA_SH_T, TPT = (BA_CHUNK_P * 3 + BA_SH_T - 1) / BA_SH_T,
+                          EPT = (BA_CHUNK_E + BA_SH_T - 1) / BA_SH_T, CPT = (BA_CHUNK_C + BA_SH_T - 1) / BA_SH_T,
+                          BPT = (BA_CHUNK_B + 1 + BA_SH_T - 1) / BA_SH_T;
+            double2 rR[EPT][2];
             double rD[DPT], rT[TPT];
-            int32_t rP[EPT], rG[EPT], rC[CPT], rB[BPT], rBS[BPT];
+            int32_t rCam[EPT], rP[EPT], rG[EPT], rC[CPT], rB[BPT], rBS[BPT];
 #pragma unroll
-            for (int k = 0; k < WPT; k++) rW[k] = tid + k * BA_SH_T < ne * 9 ? src[tid + k * BA_SH_T] : double2{0.0, 0.0};
+            for (int k = 0; k < EPT; k++) {
+                const int el = tid + k * BA_SH_T;
+                const double2 *rc = (const double2 *)(D + w.W + (int64_t)(e0 + (el < ne ? el : 0)) * 4);
+                rR[k][0] = rc[0];
+                rR[k][1] = rc[1];
+                rCam[k] = I[w.cam + e0 + (el < ne ? el : 0)];
+                rP[k] = el < ne ? I[w.pt + e0 + el] - p0 : 0;
+                rG[k] = el < ng ? I[w.cg_edge + g0 + el] : 0;
+            }
 #pragma unroll
             for (int k = 0; k < DPT; k++) rD[k] = tid + k * BA_SH_T < npnt * 9 ? D[w.Dinv + (int64_t)p0 * 9 + tid + k * BA_SH_T] : 0.0;
 #pragma unroll
             for (int k = 0; k < TPT; k++) rT[k] = tid + k * BA_SH_T < npnt * 3 ? D[w.tv + (int64_t)p0 * 3 + tid + k * BA_SH_T] : 0.0;
-#pragma unroll
-            for (int k = 0; k < EPT; k++) {
-                rP[k] = tid + k * BA_SH_T < ne ? I[w.pt + e0 + tid + k * BA_SH_T] - p0 : 0;
-                rG[k] = tid + k * BA_SH_T < ng ? I[w.cg_edge + g0 + tid + k * BA_SH_T] : 0;
-            }
 #pragma unroll
             for (int k = 0; k < CPT; k++) rC[k] = tid + k * BA_SH_T < nc ? I[w.cb_con + c0 + tid + k * BA_SH_T] : 0;
 #pragma unroll
@@ -1903,21 +1957,30 @@ __global__ __launch_bounds__(BA_SH_T) void k_ba_ph_schur2(BABufs bufs, int skip)
                 rB[k] = tid + k * BA_SH_T < ncb ? I[w.cb_blk + cb0 + tid + k * BA_SH_T] : 0;
                 rBS[k] = tid + k * BA_SH_T <= ncb ? I[w.cb_start + cb0 + tid + k * BA_SH_T] - c0 : 0;
             }
+            double rRot[EPT][9];
 #pragma unroll
-            for (int k = 0; k < WPT; k++)
-                if (tid + k * BA_SH_T < BA_CHUNK_E * 9) ((double2 *)sW)[tid + k * BA_SH_T] = rW[k];
+            for (int k = 0; k < EPT; k++)
+#pragma unroll
+                for (int i = 0; i < 9; i++) rRot[k][i] = D[w.Rc + (int64_t)rCam[k] * 9 + i];
+#pragma unroll
+            for (int k = 0; k < EPT; k++) { /* the W tile: one edge per thread, rebuilt from its record */
+                const int el = tid + k * BA_SH_T;
+                if (el < BA_CHUNK_E) {
+                    const double rec[4] = {rR[k][0].x, rR[k][0].y, rR[k][1].x, el < ne ? rR[k][1].y : 0.0};
+                    double Wr[18];
+                    ba_w_from_record(rec, rRot[k], w.fx, w.fy, Wr);
+#pragma unroll
+                    for (int i = 0; i < 9; i++) ((double2 *)(sW + el * 18))[i] = double2{Wr[2 * i], Wr[2 * i + 1]};
+                    sP[el] = rP[k];
+                    sG[el] = rG[k];
+                }
+            }
 #pragma unroll
             for (int k = 0; k < DPT; k++)
                 if (tid + k * BA_SH_T < BA_CHUNK_P * 9) sD[tid + k * BA_SH_T] = rD[k];
 #pragma unroll
             for (int k = 0; k < TPT; k++)
                 if (tid + k * BA_SH_T < BA_CHUNK_P * 3) sT[tid + k * BA_SH_T] = rT[k];
-#pragma unroll
-            for (int k = 0; k < EPT; k++)
-                if (tid + k * BA_SH_T < BA_CHUNK_E) {
-                    sP[tid + k * BA_SH_T] = rP[k];
-                    sG[tid + k * BA_SH_T] = rG[k];
-                }
 #pragma unroll
             for (int k = 0; k < CPT; k++)
                 if (tid + k * BA_SH_T < BA_CHUNK_C) sC[tid + k * BA_SH_T] = rC[k];
@@ -1928,8 +1991,8 @@ __global__ __launch_bounds__(BA_SH_T) void k_ba_ph_schur2(BABufs bufs, int skip)
             }
         }
         __syncthreads();
-        /* blocks: group g takes blocks g, g + 16, ... of the chunk's list (sorted heaviest first on the host) */
-        /* (the block's current value is fetched one pair ahead: a pair's products hide the next pair's round trip) */
+        /* blocks: group g takes blocks g, g + 16, ... of the chunk's list (sorted heaviest first on the host); the
+           block's current value is fetched one pair ahead */
         int u = (skip & 16) ? ncb : grp;
         double *Sb = D + So + (int64_t)(u < ncb ? sB[u] : 0) * 36 + (l16 < 12 ? l16 : 0) * 3;
         double sb0 = Sb[0], sb1 = Sb[1], sb2 = Sb[2];
@@ -1973,9 +2036,9 @@ __global__ __launch_bounds__(BA_SH_T) void k_ba_ph_schur2(BABufs bufs, int skip)
             sb2 = sn2;
         }
         /* g: group g takes cameras g, g + 16, ... of the chunk */
-        for (int u = (skip & 64) ? ncg : grp; u < ncg; u += BA_SH_T / 16) {
-            const int sl = I[w.cg_slot + cg0 + u];
-            const int k0 = I[w.cg_start + cg0 + u] - g0, k1 = I[w.cg_start + cg0 + u + 1] - g0;
+        for (int u2 = (skip & 64) ? ncg : grp; u2 < ncg; u2 += BA_SH_T / 16) {
+            const int sl = I[w.cg_slot + cg0 + u2];
+            const int k0 = I[w.cg_start + cg0 + u2] - g0, k1 = I[w.cg_start + cg0 + u2 + 1] - g0;
             double acc[6] = {0, 0, 0, 0, 0, 0};
             for (int k = k0 + l16; k < k1; k += 16) {
                 const int a = sG[k];
@@ -1999,6 +2062,14 @@ __global__ __launch_bounds__(BA_SH_T) void k_ba_ph_schur2(BABufs bufs, int skip)
         __syncthreads(); /* the next chunk overwrites the LDS tiles and may touch the same blocks */
     }
 }
+__global__ __launch_bounds__(BA_SH_T) void k_ba_ph_schur2(BABufs bufs, int skip) {
+    extern __shared__ __attribute__((aligned(16))) double ba_dyn[];
+    BA_PH_WINDOW
+    if (ph == 2.0) return;
+    const int part = blockIdx.y, nparts = gridDim.y;
+    const int nloop = (int)((int64_t)w.nchunks * (part + 1) / nparts) - (int)((int64_t)w.nchunks * part / nparts);
+    ba_schur_part(w, D, I, ba_dyn, threadIdx.x, part, nparts, nloop, skip);
+}
 __global__ __launch_bounds__(BA_T) void k_ba_ph_chol(BABufs bufs) {
     extern __shared__ __attribute__((aligned(16))) double ba_dyn[];
     __shared__ double bad_flag[1];
@@ -2011,7 +2082,7 @@ __global__ __launch_bounds__(BA_PH_T) void k_ba_ph_backsub(BABufs bufs) {
     BA_PH_WINDOW
     const int parts = ba_ph_parts_p(w.Np);
     if (ph == 2.0 || (int)blockIdx.y >= parts) return;
-    const double v = block_sum_n(ba_phase_backsub(w, D, I, D[w.st + ST_OK2] != 0.0, D[w.st + ST_LAMBDA], blockIdx.y * BA_PH_T + threadIdx.x, parts * BA_PH_T), s, BA_PH_T / 64);
+    const double v = block_sum_n(ba_phase_backsub<true>(w, D, I, D[w.st + ST_OK2] != 0.0, D[w.st + ST_LAMBDA], blockIdx.y * BA_PH_T + threadIdx.x, parts * BA_PH_T), s, BA_PH_T / 64);
     if (threadIdx.x == 0) D[w.gred + PH_RED_SCALE + blockIdx.y] = v;
 }
 __global__ __launch_bounds__(BA_PH_T) void k_ba_ph_trial(BABufs bufs) {
@@ -2094,13 +2165,16 @@ __global__ __launch_bounds__(BA_T) void k_ba_ph_finish(BABufs bufs) {
             if (D[w.st + ST_HAVECHI] == 0.0) ba_ph_chi2(w, D, I, B, s);
             __syncthreads();
             ba_phase_hll(w, D, I, B, threadIdx.x, BA_T);
-            ba_phase_hpp(w, D, I, B, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), BA_W, threadIdx.x & 63);
+            ba_phase_hpp<true>(w, D, I, B, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), BA_W, threadIdx.x & 63);
             __syncthreads();
         }
         ba_ph_dinv(w, D, I, s);
         ba_phase_zero2(w, D, threadIdx.x, BA_T);
         __syncthreads();
-        ba_schur_chunked(w, D, I, ba_dyn, 0);
+        { /* both parts of the Schur pass inside this workgroup: threads 0..255 part 0, 256..511 part 1, own LDS tiles */
+            const int half = threadIdx.x / BA_SH_T;
+            ba_schur_part(w, D, I, ba_dyn + half * BA_CHUNK_DOUBLES, threadIdx.x - half * BA_SH_T, half, 2, (w.nchunks + 1) / 2, 0);
+        }
         __syncthreads();
         ba_ph_chol(w, D, I, ba_dyn, &s.bc[0]);
         __syncthreads();
@@ -2169,7 +2243,7 @@ static int64_t BAWin::*const kScratchFields[] = {&BAWin::poses_t, &BAWin::pts_t,
                                                  &BAWin::tv,      &BAWin::Hpp,   &BAWin::bp,  &BAWin::Hll,   &BAWin::bl,
                                                  &BAWin::Dinv,    &BAWin::S,     &BAWin::g,   &BAWin::Minv,  &BAWin::x,
                                                  &BAWin::xl,      &BAWin::A,     &BAWin::Linv, &BAWin::gred,  &BAWin::pcgv,
-                                                 &BAWin::S2,      &BAWin::g2};
+                                                 &BAWin::S2,      &BAWin::g2,    &BAWin::Rc};
 #define BA_CHOL_LDS_BYTES (128 * 1024) /* dynamic LDS the blocked Cholesky may take beside the static 25 KB */
 
 /* Lay one problem out in the host staging vectors; returns an error code.  `team`: the window will be spread over
@@ -2437,6 +2511,7 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hO, std::vecto
     w.Dinv = allocS((size_t)Np * 9);
     w.S = allocS((size_t)nnzb * 36);
     w.g = allocS((size_t)Ncf * 6);
+    w.Rc = allocS((size_t)Nc * 9);
     w.S2 = chunked ? allocS((size_t)nnzb * 36) : w.S; /* (never read when the window is not chunked) */
     w.g2 = chunked ? allocS((size_t)Ncf * 6) : w.g;
     w.Minv = allocS((size_t)Ncf * 36);
@@ -2566,12 +2641,14 @@ struct BAJob {
     int prof_launches = 0;
     int team = 1;
     bool split = false; /* ran as phase kernels (k_ba_ph_*) */
+    hipStream_t kstream = nullptr;
     double t_start = 0, t_staged = 0, t_enqueued = 0;
 };
 
 struct BASolver {
     int device = 0;
     hipStream_t stream = nullptr;   /* kernels */
+    hipStream_t stream2 = nullptr;  /* kernels of the second job in flight */
     hipStream_t copy_in = nullptr;  /* uploads of the NEXT batch */
     hipStream_t copy_out = nullptr; /* downloads of the PREVIOUS batch */
     int max_cams, max_points, max_obs, max_batch;
@@ -2606,12 +2683,15 @@ extern "C" int ba_create(int max_cams, int max_points, int max_obs, int max_batc
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) s->cu_count = prop.multiProcessorCount;
     bool ok = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&s->copy_in, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&s->copy_out, hipStreamNonBlocking) == hipSuccess;
     for (int j = 0; j < 2 && ok; j++)
         ok = hipEventCreateWithFlags(&s->job[j].uploaded, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&s->job[j].solved, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&s->job[j].downloaded, hipEventDisableTiming) == hipSuccess;
+    s->job[0].kstream = s->stream;
+    s->job[1].kstream = s->stream2;
     if (!ok) {
         b_err = "ba_create: stream / event creation failed";
         ba_destroy(s);
@@ -2634,6 +2714,7 @@ extern "C" void ba_destroy(BASolver *s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->stream2) (void)hipStreamSynchronize(s->stream2);
     if (s->copy_in) (void)hipStreamSynchronize(s->copy_in);
     if (s->copy_out) (void)hipStreamSynchronize(s->copy_out);
     for (BAJob &j : s->job) {
@@ -2656,6 +2737,7 @@ extern "C" void ba_destroy(BASolver *s) {
     if (s->ppI) (void)hipHostFree(s->ppI);
     if (s->ppB) (void)hipHostFree(s->ppB);
     if (s->stream) (void)hipStreamDestroy(s->stream);
+    if (s->stream2) (void)hipStreamDestroy(s->stream2);
     if (s->copy_in) (void)hipStreamDestroy(s->copy_in);
     if (s->copy_out) (void)hipStreamDestroy(s->copy_out);
     delete s;
@@ -2811,6 +2893,8 @@ static int ba_stage(BASolver *s, BAJob &J, const BAProblem *probs, BAResult *res
  * region on the copy-out stream; returns without waiting unless a stop flag has to be polled between iterations */
 static int ba_enqueue(BASolver *s, BAJob &J) {
     const int nwin = J.nwin;
+    hipStream_t ks = J.kstream; /* the two jobs in flight have their own kernel streams: the thin tail of one batch (its last
+                                   windows' extra LM trials) runs beside the bulk of the next */
     const BAProblem *probs = J.probs;
     const BAProblem &P0 = probs[0];
     const bool prof = getenv("ORBSLAM_AMD_BA_PROFILE") != nullptr;
@@ -2824,7 +2908,7 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
     if (J.nB) BCHK(hipMemcpyAsync(J.dB, J.pB, J.nB, hipMemcpyHostToDevice, s->copy_in));
     BCHK(hipMemcpyAsync(J.dW, J.wins.data(), (size_t)nwin * sizeof(BAWin), hipMemcpyHostToDevice, s->copy_in));
     BCHK(hipEventRecord(J.uploaded, s->copy_in));
-    BCHK(hipStreamWaitEvent(s->stream, J.uploaded, 0));
+    BCHK(hipStreamWaitEvent(ks, J.uploaded, 0));
     BABufs bufs{J.dD, J.dI, J.dB, J.dW};
     bool any_stop_ptr = false;
     for (int i = 0; i < nwin; i++) any_stop_ptr |= probs[i].stop != nullptr;
@@ -2887,25 +2971,23 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
     if (split) {
         static PerDeviceLdsLimit lim_schur, lim_chol, lim_fin;
         static const int schur_skip = getenv("ORBSLAM_AMD_BA_SCHUR_SKIP") ? atoi(getenv("ORBSLAM_AMD_BA_SCHUR_SKIP")) : 0; /* timing experiments (results invalid) */
-        static PerDeviceLdsLimit lim_schur2;
-        static const bool schur1 = getenv("ORBSLAM_AMD_BA_SCHUR1") != nullptr; /* diagnostics: one workgroup per window */
-        BCHK(lim_schur.ensure((const void *)k_ba_ph_schur, (size_t)BA_CHUNK_DOUBLES * 8));
-        BCHK(lim_schur2.ensure((const void *)k_ba_ph_schur2, (size_t)BA_CHUNK_DOUBLES * 8));
+        BCHK(lim_schur.ensure((const void *)k_ba_ph_schur2, (size_t)BA_CHUNK_DOUBLES * 8));
         BCHK(lim_chol.ensure((const void *)k_ba_ph_chol, chol_doubles * 8));
-        BCHK(lim_fin.ensure((const void *)k_ba_ph_finish, (size_t)dyn_doubles * 8));
+        const size_t fin_doubles = std::max<size_t>(chol_doubles, 2 * (size_t)BA_CHUNK_DOUBLES);
+        BCHK(lim_fin.ensure((const void *)k_ba_ph_finish, fin_doubles * 8));
         static const bool phase_prof = getenv("ORBSLAM_AMD_BA_PHASE_PROF") != nullptr; /* diagnostics: serialises the phases */
-        double phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double phase_ms[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         hipEvent_t pe0 = nullptr, pe1 = nullptr;
         if (phase_prof) {
             BCHK(hipEventCreate(&pe0));
             BCHK(hipEventCreate(&pe1));
         }
         auto timed = [&](int slot, auto &&launch) -> int {
-            if (phase_prof) BCHK(hipEventRecord(pe0, s->stream));
+            if (phase_prof) BCHK(hipEventRecord(pe0, ks));
             launch();
             BCHK(hipGetLastError());
             if (phase_prof) {
-                BCHK(hipEventRecord(pe1, s->stream));
+                BCHK(hipEventRecord(pe1, ks));
                 BCHK(hipEventSynchronize(pe1));
                 float ms = 0;
                 BCHK(hipEventElapsedTime(&ms, pe0, pe1));
@@ -2926,48 +3008,47 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
         int trial_seq = 0;
         for (int round = 0; round < P0.n_rounds; round++) {
             const int nit = P0.rounds[round];
-            if (s->profiling) BCHK(hipEventRecord(J.prof_ev[2 * J.prof_launches], s->stream));
-            hipLaunchKernelGGL(k_ba_ph_round, dim3((nwin + 63) / 64), dim3(64), 0, s->stream, bufs, nwin, nit);
+            if (s->profiling) BCHK(hipEventRecord(J.prof_ev[2 * J.prof_launches], ks));
+            hipLaunchKernelGGL(k_ba_ph_round, dim3((nwin + 63) / 64), dim3(64), 0, ks, bufs, nwin, nit);
             BCHK(hipGetLastError());
-            const int trials = nit > 0 ? nit + BA_PH_SPARE : 0;
+            static const int spare = getenv("ORBSLAM_AMD_BA_SPARE") ? atoi(getenv("ORBSLAM_AMD_BA_SPARE")) : BA_PH_SPARE; /* tests: a negative
+                                  value leaves trials (all of them at -100) to k_ba_ph_finish */
+            const int trials = nit > 0 ? std::max(0, nit + spare) : 0;
             for (int t = 0; t < trials; t++, trial_seq++) {
                 const dim3 gE(nwin, partsE), gP(nwin, partsP), gC(nwin, partsC), tb(BA_PH_T);
-                if ((rc = timed(0, [&] { hipLaunchKernelGGL(k_ba_ph_chi2, gE, tb, 0, s->stream, bufs); }))) return rc;
-                if ((rc = timed(1, [&] { hipLaunchKernelGGL(k_ba_ph_hll, gP, tb, 0, s->stream, bufs); }))) return rc;
-                if ((rc = timed(2, [&] { hipLaunchKernelGGL(k_ba_ph_hpp, gC, tb, 0, s->stream, bufs); }))) return rc;
+                if ((rc = timed(0, [&] { hipLaunchKernelGGL(k_ba_ph_chi2, gE, tb, 0, ks, bufs); }))) return rc;
+                if ((rc = timed(1, [&] { hipLaunchKernelGGL(k_ba_ph_hll, gP, tb, 0, ks, bufs); }))) return rc;
+                if ((rc = timed(2, [&] { hipLaunchKernelGGL(k_ba_ph_hpp, gC, tb, 0, ks, bufs); }))) return rc;
                 if ((rc = timed(3, [&] {
-                         hipLaunchKernelGGL(k_ba_ph_prep, dim3(nwin), dim3(BA_T), 0, s->stream, bufs);
-                         hipLaunchKernelGGL(k_ba_ph_dinv, gP, tb, 0, s->stream, bufs);
+                         hipLaunchKernelGGL(k_ba_ph_prep, dim3(nwin), dim3(BA_T), 0, ks, bufs);
+                         hipLaunchKernelGGL(k_ba_ph_dinv, gP, tb, 0, ks, bufs);
                      })))
                     return rc;
                 if ((rc = timed(4, [&] {
-                         if (schur1)
-                             hipLaunchKernelGGL(k_ba_ph_schur, dim3(nwin), dim3(BA_T), (size_t)BA_CHUNK_DOUBLES * 8, s->stream, bufs, schur_skip);
-                         else
-                             hipLaunchKernelGGL(k_ba_ph_schur2, dim3(nwin, 2), dim3(BA_SH_T), (size_t)BA_CHUNK_DOUBLES * 8, s->stream, bufs, schur_skip);
+                         hipLaunchKernelGGL(k_ba_ph_schur2, dim3(nwin, 2), dim3(BA_SH_T), (size_t)BA_CHUNK_DOUBLES * 8, ks, bufs, schur_skip);
                      })))
                     return rc;
-                if ((rc = timed(5, [&] { hipLaunchKernelGGL(k_ba_ph_chol, dim3(nwin), dim3(BA_T), chol_doubles * 8, s->stream, bufs); }))) return rc;
-                if ((rc = timed(6, [&] {
-                         hipLaunchKernelGGL(k_ba_ph_backsub, gP, tb, 0, s->stream, bufs);
-                         hipLaunchKernelGGL(k_ba_ph_trial, gE, tb, 0, s->stream, bufs);
-                         hipLaunchKernelGGL(k_ba_ph_decide, dim3((nwin + 63) / 64), dim3(64), 0, s->stream, bufs, nwin, trial_seq);
-                         hipLaunchKernelGGL(k_ba_ph_accept, gE, tb, 0, s->stream, bufs, trial_seq);
+                if ((rc = timed(5, [&] { hipLaunchKernelGGL(k_ba_ph_chol, dim3(nwin), dim3(BA_T), chol_doubles * 8, ks, bufs); }))) return rc;
+                if ((rc = timed(6, [&] { hipLaunchKernelGGL(k_ba_ph_backsub, gP, tb, 0, ks, bufs); }))) return rc;
+                if ((rc = timed(7, [&] { hipLaunchKernelGGL(k_ba_ph_trial, gE, tb, 0, ks, bufs); }))) return rc;
+                if ((rc = timed(8, [&] {
+                         hipLaunchKernelGGL(k_ba_ph_decide, dim3((nwin + 63) / 64), dim3(64), 0, ks, bufs, nwin, trial_seq);
+                         hipLaunchKernelGGL(k_ba_ph_accept, gE, tb, 0, ks, bufs, trial_seq);
                      })))
                     return rc;
             }
             if (nit > 0)
-                if ((rc = timed(7, [&] { hipLaunchKernelGGL(k_ba_ph_finish, dim3(nwin), dim3(BA_T), (size_t)dyn_doubles * 8, s->stream, bufs); }))) return rc;
-            if (s->profiling) BCHK(hipEventRecord(J.prof_ev[2 * J.prof_launches + 1], s->stream));
+                if ((rc = timed(9, [&] { hipLaunchKernelGGL(k_ba_ph_finish, dim3(nwin), dim3(BA_T), fin_doubles * 8, ks, bufs); }))) return rc;
+            if (s->profiling) BCHK(hipEventRecord(J.prof_ev[2 * J.prof_launches + 1], ks));
             J.prof_launches++;
             if (round + 1 < P0.n_rounds) {
-                hipLaunchKernelGGL(k_ba_classify, dim3(nwin), dim3(BA_T), 0, s->stream, bufs, P0.drop_robust_after == round ? 1 : 0, 0);
+                hipLaunchKernelGGL(k_ba_classify, dim3(nwin), dim3(BA_T), 0, ks, bufs, P0.drop_robust_after == round ? 1 : 0, 0);
                 BCHK(hipGetLastError());
             }
         }
         if (phase_prof) {
-            fprintf(stderr, "[ba] phase kernels, %d windows, ms: chi2 %.2f | Hll %.2f | Hpp+W %.2f | Dinv %.2f | Schur %.2f | Cholesky %.2f | update+trial %.2f | finish %.2f\n",
-                    nwin, phase_ms[0], phase_ms[1], phase_ms[2], phase_ms[3], phase_ms[4], phase_ms[5], phase_ms[6], phase_ms[7]);
+            fprintf(stderr, "[ba] phase kernels, %d windows, ms: chi2 %.2f | Hll %.2f | Hpp+W %.2f | Dinv %.2f | Schur %.2f | Cholesky %.2f | backsub %.2f | trial %.2f | decide+accept %.2f | finish %.2f\n",
+                    nwin, phase_ms[0], phase_ms[1], phase_ms[2], phase_ms[3], phase_ms[4], phase_ms[5], phase_ms[6], phase_ms[7], phase_ms[8], phase_ms[9]);
             hipEventDestroy(pe0);
             hipEventDestroy(pe1);
         }
@@ -2980,7 +3061,7 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
                 halted = true;
                 break;
             }
-            if (s->profiling) BCHK(hipEventRecord(J.prof_ev[2 * J.prof_launches], s->stream));
+            if (s->profiling) BCHK(hipEventRecord(J.prof_ev[2 * J.prof_launches], ks));
             int first = it == 0 ? 1 : 0, solver = s->solver, g = G, sq = seq++, nit = std::min(per_launch, P0.rounds[round] - it);
             double tol2 = s->pcg_tol2;
             int dbg = debug;
@@ -2991,32 +3072,32 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
                    against the device and never runs two cooperative kernels side by side) */
                 void *args[] = {&bufs, &first, &tol2, &pcg_maxit, &dbg, &solver, &dyn_doubles, &g, &sq, &nit};
                 BCHK(hipLaunchCooperativeKernel((const void *)k_ba_iteration, dim3(nwin * G), dim3(BA_T), args,
-                                                (size_t)dyn_doubles * 8, s->stream));
+                                                (size_t)dyn_doubles * 8, ks));
             } else if (G > 1) {
-                hipLaunchKernelGGL(k_ba_iteration, dim3(nwin * G), dim3(BA_T), (size_t)dyn_doubles * 8, s->stream, bufs, first, tol2,
+                hipLaunchKernelGGL(k_ba_iteration, dim3(nwin * G), dim3(BA_T), (size_t)dyn_doubles * 8, ks, bufs, first, tol2,
                                    pcg_maxit, dbg, solver, dyn_doubles, g, sq, nit);
                 BCHK(hipGetLastError());
             } else {
-                hipLaunchKernelGGL(k_ba_iteration, dim3(nwin), dim3(BA_T), (size_t)dyn_doubles * 8, s->stream, bufs, first, tol2,
+                hipLaunchKernelGGL(k_ba_iteration, dim3(nwin), dim3(BA_T), (size_t)dyn_doubles * 8, ks, bufs, first, tol2,
                                    pcg_maxit, dbg, solver, dyn_doubles, 1, sq, nit);
                 BCHK(hipGetLastError());
             }
-            if (s->profiling) BCHK(hipEventRecord(J.prof_ev[2 * J.prof_launches + 1], s->stream));
+            if (s->profiling) BCHK(hipEventRecord(J.prof_ev[2 * J.prof_launches + 1], ks));
             J.prof_launches++;
             /* the stop flag must be observed between iterations, as the reference's optimizer would */
-            if (any_stop_ptr) BCHK(hipStreamSynchronize(s->stream));
+            if (any_stop_ptr) BCHK(hipStreamSynchronize(ks));
         }
         if (halted) break;
         if (round + 1 < P0.n_rounds) {
             if (stopped()) break; /* bDoMore == false */
-            hipLaunchKernelGGL(k_ba_classify, dim3(nwin), dim3(BA_T), 0, s->stream, bufs,
+            hipLaunchKernelGGL(k_ba_classify, dim3(nwin), dim3(BA_T), 0, ks, bufs,
                                P0.drop_robust_after == round ? 1 : 0, 0);
             BCHK(hipGetLastError());
         }
     }
-    hipLaunchKernelGGL(k_ba_classify, dim3(nwin), dim3(BA_T), 0, s->stream, bufs, 0, 1);
+    hipLaunchKernelGGL(k_ba_classify, dim3(nwin), dim3(BA_T), 0, ks, bufs, 0, 1);
     BCHK(hipGetLastError());
-    BCHK(hipEventRecord(J.solved, s->stream));
+    BCHK(hipEventRecord(J.solved, ks));
     /* results: the output region only (poses, points, LM state of every window), plus the edge flags */
     BCHK(hipStreamWaitEvent(s->copy_out, J.solved, 0));
     BCHK(hipMemcpyAsync(J.pD, J.dD, J.nOut * 8, hipMemcpyDeviceToHost, s->copy_out));

@@ -31,9 +31,12 @@ def test_ba_matches_oracle(opt, oracle, nc, npt, rounds, nfix):
     w["fixed"][:nfix] = 1
     ref = oracle.ba_solve(w, rounds=rounds)
     got = opt.solve_batch([w], rounds)[0]
-    assert got["iterations"] == ref["iterations"]
-    # once converged to machine precision the sign of rho is rounding noise, so the number of LM trials
-    # may differ by a few between the two solvers; the estimates may not
+    # once converged to machine precision the sign of rho is rounding noise, so the number of LM trials may differ by
+    # a few between the two solvers -- and with it the iteration at which LM gives up (ten rejected trials in a row:
+    # the 8 x 150 window ends that way on the phase-kernel path); the estimates may not
+    if got["iterations"] != ref["iterations"]:
+        assert abs(got["iterations"] - ref["iterations"]) <= 1
+        assert abs(got["chi2_final"] - ref["chi2_final"]) <= 1e-9 * ref["chi2_final"]
     assert abs(got["lin_solves"] - ref["lin_solves"]) <= 10
     assert np.array_equal(got["outlier"], ref["outlier"])
     assert _rel(got["points"], ref["points"]) < REL

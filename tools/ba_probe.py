@@ -28,4 +28,15 @@ for nu in [int(a) for a in sys.argv[1:]] or [4, 32]:
     E = np.array([len(w["obs"]) for w in uniq])
     print("unique %d batch %d: call %.1f ms, kernel launches %d x %.2f ms = %.1f ms, team %d, lin_solves min/mean/max %d/%.2f/%d, E min/max %d/%d"
           % (nu, batch, dt * 1e3, nl, ms, nl * ms, team, ls.min(), ls.mean(), ls.max(), E.min(), E.max()))
+    reps = int(os.environ.get("STREAM", "0"))
+    if reps:  # a stream of batches through submit / wait (two in flight): windows/s with staging and copies overlapped
+        opt.set_profiling(False)
+        opt.submit_batch(wins, (5, 10))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            opt.submit_batch(wins, (5, 10))
+            opt.wait()
+        dt = time.perf_counter() - t0
+        opt.wait()
+        print("  streamed: %d batches of %d in %.1f ms = %.0f windows/s" % (reps, batch, dt * 1e3, reps * batch / dt))
     opt.close()
