@@ -720,21 +720,35 @@ __device__ __noinline__ bool ba_chol_solve(const BAWin &w, double *D, const int3
  * the half of its values that its lane bit selects and adds the partner's copy of that half -- 24 + 12 + 6 + 3 = 45
  * exchanges instead of the 144 of four full butterflies (each f64 exchange is two LDS-crossbar permutes).  Lane q ends
  * up with the totals of entries 3q, 3q+1, 3q+2 (lanes 12..15: padding). */
+/* value of `v` in lane (lane ^ M), M = 1, 2, 4, 8: data-parallel-primitive moves inside a row of 16 lanes -- VALU
+ * instructions on each of the four SIMDs, where a ds_bpermute pair per f64 goes through the CU's one LDS pipe (the 90
+ * bpermutes that ended every (block, chunk) pair of the Schur pass were that pipe's largest customer).
+ * xor 1 / xor 2: quad_perm; xor 8: row_ror:8; xor 4 = row_half_mirror (i -> i ^ 7) then quad_perm [3,2,1,0] (i -> i ^ 3). */
+template <int M> __device__ __forceinline__ int xchg16_b32(int v) {
+    if (M == 1) return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);
+    if (M == 2) return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);
+    if (M == 8) return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0xF, false);
+    const int h = __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false);
+    return __builtin_amdgcn_update_dpp(h, h, 0x1B, 0xF, 0xF, false);
+}
+template <int M> __device__ __forceinline__ double xchg16(double v) {
+    return __hiloint2double(xchg16_b32<M>(__double2hiint(v)), xchg16_b32<M>(__double2loint(v)));
+}
 __device__ __forceinline__ void group16_reduce36(const double *acc, int l16, double &o0, double &o1, double &o2) {
     double a24[24], a12[12], a6[6];
     const bool h8 = l16 & 8, h4 = l16 & 4, h2 = l16 & 2, h1 = l16 & 1;
 #pragma unroll
     for (int i = 0; i < 24; i++) {
         const double lo = acc[i], hi = (24 + i < 36) ? acc[24 + i] : 0.0;
-        a24[i] = (h8 ? hi : lo) + __shfl_xor(h8 ? lo : hi, 8);
+        a24[i] = (h8 ? hi : lo) + xchg16<8>(h8 ? lo : hi);
     }
 #pragma unroll
-    for (int i = 0; i < 12; i++) a12[i] = (h4 ? a24[12 + i] : a24[i]) + __shfl_xor(h4 ? a24[i] : a24[12 + i], 4);
+    for (int i = 0; i < 12; i++) a12[i] = (h4 ? a24[12 + i] : a24[i]) + xchg16<4>(h4 ? a24[i] : a24[12 + i]);
 #pragma unroll
-    for (int i = 0; i < 6; i++) a6[i] = (h2 ? a12[6 + i] : a12[i]) + __shfl_xor(h2 ? a12[i] : a12[6 + i], 2);
-    o0 = (h1 ? a6[3] : a6[0]) + __shfl_xor(h1 ? a6[0] : a6[3], 1);
-    o1 = (h1 ? a6[4] : a6[1]) + __shfl_xor(h1 ? a6[1] : a6[4], 1);
-    o2 = (h1 ? a6[5] : a6[2]) + __shfl_xor(h1 ? a6[2] : a6[5], 1);
+    for (int i = 0; i < 6; i++) a6[i] = (h2 ? a12[6 + i] : a12[i]) + xchg16<2>(h2 ? a12[i] : a12[6 + i]);
+    o0 = (h1 ? a6[3] : a6[0]) + xchg16<1>(h1 ? a6[0] : a6[3]);
+    o1 = (h1 ? a6[4] : a6[1]) + xchg16<1>(h1 ? a6[1] : a6[4]);
+    o2 = (h1 ? a6[5] : a6[2]) + xchg16<1>(h1 ? a6[2] : a6[5]);
 }
 
 __device__ __noinline__ void ba_schur_chunked(const BAWin &w, double *D, const int32_t *I, double *ba_dyn, int debug) {
@@ -2641,14 +2655,12 @@ struct BAJob {
     int prof_launches = 0;
     int team = 1;
     bool split = false; /* ran as phase kernels (k_ba_ph_*) */
-    hipStream_t kstream = nullptr;
     double t_start = 0, t_staged = 0, t_enqueued = 0;
 };
 
 struct BASolver {
     int device = 0;
     hipStream_t stream = nullptr;   /* kernels */
-    hipStream_t stream2 = nullptr;  /* kernels of the second job in flight */
     hipStream_t copy_in = nullptr;  /* uploads of the NEXT batch */
     hipStream_t copy_out = nullptr; /* downloads of the PREVIOUS batch */
     int max_cams, max_points, max_obs, max_batch;
@@ -2683,15 +2695,12 @@ extern "C" int ba_create(int max_cams, int max_points, int max_obs, int max_batc
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) s->cu_count = prop.multiProcessorCount;
     bool ok = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&s->copy_in, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&s->copy_out, hipStreamNonBlocking) == hipSuccess;
     for (int j = 0; j < 2 && ok; j++)
         ok = hipEventCreateWithFlags(&s->job[j].uploaded, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&s->job[j].solved, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&s->job[j].downloaded, hipEventDisableTiming) == hipSuccess;
-    s->job[0].kstream = s->stream;
-    s->job[1].kstream = s->stream2;
     if (!ok) {
         b_err = "ba_create: stream / event creation failed";
         ba_destroy(s);
@@ -2714,7 +2723,6 @@ extern "C" void ba_destroy(BASolver *s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    if (s->stream2) (void)hipStreamSynchronize(s->stream2);
     if (s->copy_in) (void)hipStreamSynchronize(s->copy_in);
     if (s->copy_out) (void)hipStreamSynchronize(s->copy_out);
     for (BAJob &j : s->job) {
@@ -2737,7 +2745,6 @@ extern "C" void ba_destroy(BASolver *s) {
     if (s->ppI) (void)hipHostFree(s->ppI);
     if (s->ppB) (void)hipHostFree(s->ppB);
     if (s->stream) (void)hipStreamDestroy(s->stream);
-    if (s->stream2) (void)hipStreamDestroy(s->stream2);
     if (s->copy_in) (void)hipStreamDestroy(s->copy_in);
     if (s->copy_out) (void)hipStreamDestroy(s->copy_out);
     delete s;
@@ -2893,8 +2900,8 @@ static int ba_stage(BASolver *s, BAJob &J, const BAProblem *probs, BAResult *res
  * region on the copy-out stream; returns without waiting unless a stop flag has to be polled between iterations */
 static int ba_enqueue(BASolver *s, BAJob &J) {
     const int nwin = J.nwin;
-    hipStream_t ks = J.kstream; /* the two jobs in flight have their own kernel streams: the thin tail of one batch (its last
-                                   windows' extra LM trials) runs beside the bulk of the next */
+    hipStream_t ks = s->stream; /* (a kernel stream per job in flight -- the thin tail of one batch beside the bulk of the next --
+                                   was measured: 5141 windows/s against 5875 with the batches back to back on one stream) */
     const BAProblem *probs = J.probs;
     const BAProblem &P0 = probs[0];
     const bool prof = getenv("ORBSLAM_AMD_BA_PROFILE") != nullptr;
