@@ -137,7 +137,8 @@ def ba_bench(dev_index, rank, world, n_windows, nc, npt, reps, barrier, max_over
     res = opt.wait()
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
-    # one synchronous call, HIP events around every k_ba_iteration launch: the roofline of the BA kernel
+    # one synchronous call, HIP events around the device work of every optimize() round (team == 0: the batch ran as
+    # phase kernels, k_ba_ph_*; otherwise one k_ba_iteration launch per round): the roofline of the BA kernels
     opt.set_profiling(True)
     t1 = time.perf_counter()
     res = opt.solve_batch(wins, (5, 10))
@@ -154,7 +155,7 @@ def ba_bench(dev_index, rank, world, n_windows, nc, npt, reps, barrier, max_over
             traffic = int(tj["ba_iteration"] * n_windows / float(tj.get("_ba_batch", n_windows)))
     except Exception:
         pass
-    roof = {"bound": "hbm", "kernel": "k_ba_iteration", "achieved": round(a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roof = {"bound": "hbm", "kernel": "k_ba_ph_* (the phase kernels of one optimize() round)" if team == 0 else "k_ba_iteration", "achieved": round(a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(a / HBM_PEAK_GBS, 5), "traffic": traffic,
             "algorithmic_bytes_per_launch": int(total_bytes / max(launches, 1)), "windows_per_launch": n_windows,
             "launches": launches, "avg_launch_ms": round(iter_ms, 4), "workgroups_per_window": team,

@@ -885,8 +885,10 @@ __device__ __noinline__ void ba_schur_chunked(const BAWin &w, double *D, const i
 #pragma unroll
             for (int r = 0; r < 6; r++) {
                 double v = acc[r];
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                v += xchg16<8>(v);
+                v += xchg16<4>(v);
+                v += xchg16<2>(v);
+                v += xchg16<1>(v);
                 acc[r] = v;
             }
             if (l16 == 0) {
@@ -1193,21 +1195,47 @@ __device__ __forceinline__ void ba_phase_hpp(const BAWin &w, double *D, const in
                 for (int i = 0; i < 9; i++) We[i] = double2{wv[2 * i], wv[2 * i + 1]};
             }
         }
-        for (int i = 0; i < 27; i++) {
-            double v = acc[i];
+        /* sum of the 27 partials over the 64 lanes: recursive halving across the four rows of 16 (28 -> 14 -> 7 values,
+           21 f64 exchanges through the LDS crossbar instead of 54), then row-local DPP moves.  Lane 0 ends up with
+           entries 0 .. 6, lanes 16, 32, 48 with the other three groups of 7 (see the store below). */
+        double a14[14], a7[7];
+        const bool h32 = lane & 32, h16 = lane & 16;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            acc[i] = v;
+        for (int i = 0; i < 14; i++) {
+            const double lo = acc[i], hi = (14 + i < 27) ? acc[14 + i] : 0.0;
+            a14[i] = (h32 ? hi : lo) + __shfl_xor(h32 ? lo : hi, 32);
         }
-        if (lane == 0) {
-            int q = 0;
-            for (int a = 0; a < 6; a++)
-                for (int bb = a; bb < 6; bb++) {
-                    D[w.Hpp + (int64_t)sl * 36 + a * 6 + bb] = acc[q];
-                    D[w.Hpp + (int64_t)sl * 36 + bb * 6 + a] = acc[q];
-                    q++;
+#pragma unroll
+        for (int i = 0; i < 7; i++) a7[i] = (h16 ? a14[7 + i] : a14[i]) + __shfl_xor(h16 ? a14[i] : a14[7 + i], 16);
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            double v = a7[i];
+            v += xchg16<8>(v);
+            v += xchg16<4>(v);
+            v += xchg16<2>(v);
+            v += xchg16<1>(v);
+            a7[i] = v;
+        }
+        if ((lane & 15) == 0) {
+            const int base = (h32 ? 14 : 0) + (h16 ? 7 : 0);
+#pragma unroll
+            for (int i = 0; i < 7; i++) {
+                const int q = base + i;
+                if (q >= 27) continue;
+                if (q >= 21) {
+                    D[w.bp + (int64_t)sl * 6 + (q - 21)] = a7[i];
+                } else {
+                    /* q-th pair (a, bb) of the upper triangle, row-major */
+                    int a = 0, rem = q;
+                    while (rem >= 6 - a) {
+                        rem -= 6 - a;
+                        a++;
+                    }
+                    const int bb = a + rem;
+                    D[w.Hpp + (int64_t)sl * 36 + a * 6 + bb] = a7[i];
+                    D[w.Hpp + (int64_t)sl * 36 + bb * 6 + a] = a7[i];
                 }
-            for (int a = 0; a < 6; a++) D[w.bp + (int64_t)sl * 6 + a] = acc[21 + a];
+            }
         }
     }
 }
@@ -2064,8 +2092,10 @@ __device__ __forceinline__ void ba_schur_part(const BAWin &w, double *D, const i
 #pragma unroll
             for (int r = 0; r < 6; r++) {
                 double v = acc[r];
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                v += xchg16<8>(v);
+                v += xchg16<4>(v);
+                v += xchg16<2>(v);
+                v += xchg16<1>(v);
                 acc[r] = v;
             }
             if (l16 == 0) {
@@ -2676,6 +2706,8 @@ struct BASolver {
     double pcg_tol2 = 1e-26; /* relative M^-1-norm of the residual, squared */
     int solver = 1;          /* 1 = dense blocked Cholesky (MFMA f64), 0 = PCG (ORBSLAM_AMD_BA_SOLVER=pcg) */
     int force_team = 0;      /* ORBSLAM_AMD_BA_TEAM: workgroups per window (0 = choose) */
+    int force_split = -1;    /* ORBSLAM_AMD_BA_SPLIT: 0 fused kernel, 1 phase kernels when eligible, -1 by batch size */
+    int spare_trials = BA_PH_SPARE; /* ORBSLAM_AMD_BA_SPARE */
     bool profiling = false;
     float last_iter_ms = 0.f; /* average k_ba_iteration launch of the last finished batch */
     int last_iter_launches = 0, last_team = 1;
@@ -2715,6 +2747,10 @@ extern "C" int ba_create(int max_cams, int max_points, int max_obs, int max_batc
     const char *sv = getenv("ORBSLAM_AMD_BA_SOLVER");
     if (sv && !strcmp(sv, "pcg")) s->solver = 0;
     if (getenv("ORBSLAM_AMD_BA_TEAM")) s->force_team = atoi(getenv("ORBSLAM_AMD_BA_TEAM"));
+    /* tests / diagnostics: 0 / 1 = fused kernel / phase kernels (when eligible) whatever the batch size; trials enqueued per
+       round beyond its iterations (a negative value leaves trials -- all of them at -100 -- to k_ba_ph_finish) */
+    if (getenv("ORBSLAM_AMD_BA_SPLIT")) s->force_split = atoi(getenv("ORBSLAM_AMD_BA_SPLIT"));
+    if (getenv("ORBSLAM_AMD_BA_SPARE")) s->spare_trials = atoi(getenv("ORBSLAM_AMD_BA_SPARE"));
     *out = s;
     return ORB_OK;
 }
@@ -2969,11 +3005,8 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
         if (w.nchunks <= 0 || w.ch_pm <= 0 || w.Ncf <= 0 || need > (size_t)dyn_doubles) split = false;
         chol_doubles = std::max(chol_doubles, need);
     }
-    {
-        static const char *force = getenv("ORBSLAM_AMD_BA_SPLIT");
-        if (force && force[0] == '0') split = false;
-        if (!(force && force[0] == '1') && nwin < BA_SPLIT_MIN_WINDOWS) split = false;
-    }
+    if (s->force_split == 0) split = false;
+    if (s->force_split != 1 && nwin < BA_SPLIT_MIN_WINDOWS) split = false;
     J.split = split;
     if (split) {
         static PerDeviceLdsLimit lim_schur, lim_chol, lim_fin;
@@ -3018,9 +3051,7 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
             if (s->profiling) BCHK(hipEventRecord(J.prof_ev[2 * J.prof_launches], ks));
             hipLaunchKernelGGL(k_ba_ph_round, dim3((nwin + 63) / 64), dim3(64), 0, ks, bufs, nwin, nit);
             BCHK(hipGetLastError());
-            static const int spare = getenv("ORBSLAM_AMD_BA_SPARE") ? atoi(getenv("ORBSLAM_AMD_BA_SPARE")) : BA_PH_SPARE; /* tests: a negative
-                                  value leaves trials (all of them at -100) to k_ba_ph_finish */
-            const int trials = nit > 0 ? std::max(0, nit + spare) : 0;
+            const int trials = nit > 0 ? std::max(0, nit + s->spare_trials) : 0;
             for (int t = 0; t < trials; t++, trial_seq++) {
                 const dim3 gE(nwin, partsE), gP(nwin, partsP), gC(nwin, partsC), tb(BA_PH_T);
                 if ((rc = timed(0, [&] { hipLaunchKernelGGL(k_ba_ph_chi2, gE, tb, 0, ks, bufs); }))) return rc;
@@ -3138,7 +3169,7 @@ static int ba_finish(BASolver *s, BAJob &J) {
             res[i].lin_solves = (int)J.pD[w.st + ST_SOLVES];
         }
     });
-    s->last_team = J.team;
+    s->last_team = J.split ? 0 : J.team;
     for (int i = 0; i < nwin; i++)
         if (J.pD[J.wins[i].st + ST_ABORT] != 0.0) {
             b_err = "ba_solve: a workgroup-team barrier timed out (window results are invalid)";

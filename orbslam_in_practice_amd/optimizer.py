@@ -104,7 +104,8 @@ class Optimizer:
         check(self._L.ba_set_profiling(self._s, 1 if on else 0))
 
     def iteration_ms(self):
-        """(average k_ba_iteration launch in ms, launches, workgroups per window) of the last finished batch"""
+        """(average device time of an optimize() round in ms, rounds timed, workgroups per window -- 0: the batch ran as
+        phase kernels) of the last finished batch"""
         ms, nl, team = C.c_float(0), C.c_int32(0), C.c_int32(0)
         check(self._L.ba_get_iteration_ms(self._s, C.byref(ms), C.byref(nl), C.byref(team)))
         return ms.value, nl.value, team.value

@@ -414,3 +414,39 @@ def test_ba_point_seen_by_every_camera_takes_the_list_path(opt, oracle):
     for w, g in zip(ws, got):
         ref = oracle.ba_solve(w, rounds=(5, 10))
         _check_estimates(g, ref)
+
+
+@pytest.mark.parametrize("spare", [None, "-100", "0"])
+def test_ba_phase_kernel_batch_path(oracle, monkeypatch, spare):
+    """a batch of more than 128 windows runs as phase kernels (an LM trial = ten kernels over all windows, the windows'
+    positions in g2o's control flow in their state records, W rebuilt from 32-byte edge records, two-part Schur pass):
+    every window within 1e-5 of the oracle -- with the default number of enqueued trials, with none (everything left to
+    the per-window finishing kernel) and with exactly one per iteration (windows with a rejected trial finish there)"""
+    import orbslam_in_practice_amd as oa
+    from orbslam_in_practice_amd import synth
+    if spare is not None:
+        monkeypatch.setenv("ORBSLAM_AMD_BA_SPARE", spare)
+    shapes = [(8, 150), (12, 400), (30, 900), (20, 300)]
+    ws = []
+    for i in range(136):
+        nc, npt = shapes[i % len(shapes)]
+        w = synth.make_ba_window(7000 + i, nc, npt)
+        w["fixed"][:1 + i % 3] = 1
+        ws.append(w)
+    o = oa.Optimizer(max_cams=32, max_points=1024, max_obs=16384, max_batch=len(ws))
+    o.set_profiling(True)
+    got = o.solve_batch(ws, (5, 10))
+    ms, launches, team = o.iteration_ms()
+    assert team == 0 and launches == 2 and ms > 0        # phase kernels; one timed interval per optimize() round
+    o.close()
+    for i, (w, g) in enumerate(zip(ws, got)):
+        if i % 4 == 0 or i < 8:                           # (the oracle takes its time: a sample of the batch)
+            _check_estimates(g, oracle.ba_solve(w, rounds=(5, 10)), converged_ok=True)
+    # the same windows one at a time (workgroup teams, fused kernel): same estimates to rounding
+    o1 = oa.Optimizer(max_cams=32, max_points=1024, max_obs=16384, max_batch=1)
+    for i in (0, 1, 2, 3, 77):
+        s1 = o1.solve_batch([ws[i]], (5, 10))[0]
+        assert np.array_equal(s1["outlier"], got[i]["outlier"])
+        assert _rel(s1["points"], got[i]["points"]) < 1e-6
+        assert _rel(s1["poses"], got[i]["poses"]) < 1e-6
+    o1.close()
