@@ -22,6 +22,7 @@ STAGE = {"k_ba_iteration": "ba_iteration", "k_pyramid": "pyramid", "k_copy_level
          "k_blur": "blur", "k_describe": "describe", "k_match_knn": "match_knn", "k_match_init": "match_resolve"}
 LAUNCHES_PER_STEP = {"pyramid": 1, "fast": 1, "quadtree": 1, "blur": 1, "describe": 1, "match_knn": 1, "match_resolve": 1,
                      "ba_iteration": 1}
+PHASE = {"FETCH_SIZE": collections.defaultdict(float), "WRITE_SIZE": collections.defaultdict(float)}
 BA_BATCH = 256  # only the one-workgroup-per-window batch launches of k_ba_iteration are tallied (grid = BA_BATCH x 512 threads)
 
 
@@ -34,6 +35,12 @@ def load(d, counter):
             continue
         name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
         if name == "k_ba_iteration" and int(r["Grid_Size"]) != BA_BATCH * 512:
+            continue
+        if name.startswith("k_ba_ph_"):  # the batch path as phase kernels: everything between two k_ba_ph_round launches is one round
+            tot["ba_iteration"] += float(r["Counter_Value"])
+            PHASE[counter][name] += float(r["Counter_Value"])
+            if name == "k_ba_ph_round":
+                calls["ba_iteration"] += 1
             continue
         if name in STAGE:
             tot[STAGE[name]] += float(r["Counter_Value"])
@@ -63,6 +70,9 @@ def main():
         res[st] = int(f + w)
         res["_" + st + "_fetch_raw_kib"] = round(fetch[st] / calls[st], 1)
         res["_" + st + "_write_kib"] = round(write[st] / max(calls_w[st], 1), 1)
+    if calls["ba_iteration"] and PHASE["FETCH_SIZE"]:  # bytes per optimize() round and phase kernel
+        res["_ba_phase_bytes"] = {k: int((PHASE["FETCH_SIZE"][k] * 2.0 + PHASE["WRITE_SIZE"].get(k, 0.0)) * 1024.0 / calls["ba_iteration"])
+                                  for k in sorted(PHASE["FETCH_SIZE"])}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res))
 
