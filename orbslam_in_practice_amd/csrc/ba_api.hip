@@ -71,7 +71,6 @@ struct BAWin {
     /* doubles */
     int64_t poses, poses_t, pts, pts_t, obs, info, err, err_t, W, tv, Hpp, bp, Hll, bl, Dinv, S, g, Minv, x, xl, st;
     int64_t A, Linv; /* dense reduced system (np x np) and inverse diagonal blocks of its Cholesky factor */
-    int64_t Hp;      /* partial Hpp / bp tables of k_ba_ph_build's workgroups (BA_BUILD_PARTS x Ncf x 27 doubles; chunked windows) */
     int64_t Rc;      /* rotation matrices of the cameras (9 doubles each), written by the camera pass of the phase-kernel path */
     int64_t S2, g2;  /* second accumulator of the Schur products and of g (phase-kernel path: the window's chunks are split
                         over two workgroups; the Cholesky assembly adds S and S2, g and g2); chunked windows only */
@@ -1906,153 +1905,6 @@ __global__ __launch_bounds__(BA_PH_T) void k_ba_ph_hpp(BABufs bufs) { /* one wav
     ba_phase_hpp<true>(w, D, I, B, blockIdx.y * (BA_PH_T / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), gridDim.y * (BA_PH_T / 64),
                  threadIdx.x & 63);
 }
-/* buildSystem in ONE pass over the edges in storage (point) order -- k_ba_ph_hll + k_ba_ph_hpp read every per-edge
- * input twice, and the camera pass reads them through the cameras' edge lists: five scattered cache lines per edge
- * for 53 useful bytes.  Here a workgroup takes a range of the window's point chunks; per chunk
- *   A  one thread per edge: flag, camera, point, error, information (coalesced), pose and point (gathers that hit),
- *      both Jacobians once; the 32-byte edge record goes out coalesced, Jj / weight / residual (15 doubles) and the
- *      edge's share of Hll / bl (9) go to LDS;
- *   B1 one thread per point adds up its (contiguous) edges' shares in edge order -> Hll, bl (the same sums, in the
- *      same order, as ba_phase_hll);
- *   B2 one thread per (camera of the chunk, entry of Hpp's upper triangle or of bp) adds up that camera's edges of the
- *      chunk from LDS (the per-chunk camera lists the g pass uses) into the workgroup's Hpp table in LDS -- one owner
- *      per entry and chunk, no atomics, fixed order.
- * The tables of a window's BA_BUILD_PARTS workgroups are added in part order by k_ba_ph_build_sum, which also writes
- * the cameras' rotations for the consumers of the records. */
-#define BA_BUILD_PARTS 2
-#define BA_BUILD_MAX_NCF 192 /* free cameras whose 27-double rows fit the LDS table beside the chunk staging */
-__global__ __launch_bounds__(BA_T) void k_ba_ph_build(BABufs bufs) {
-    extern __shared__ __attribute__((aligned(16))) double ba_dyn[];
-    BA_PH_WINDOW
-    if (ph != 0.0) return;
-    const int tid = threadIdx.x, part = blockIdx.y;
-    const int ch0 = (int)((int64_t)w.nchunks * part / gridDim.y), ch1 = (int)((int64_t)w.nchunks * (part + 1) / gridDim.y);
-    double *sJ = ba_dyn;                     /* [BA_CHUNK_E][15]: Jj (12), weight, -info * err (2) */
-    double *sH = sJ + BA_CHUNK_E * 15;       /* [BA_CHUNK_E][9] : Hll share (6 unique), bl share (3) */
-    int32_t *sG = (int32_t *)(sH + BA_CHUNK_E * 9); /* the chunk's camera lists: local edges [BA_CHUNK_E], slot and list start per camera */
-    int32_t *sGs = sG + BA_CHUNK_E, *sGk = sGs + BA_CHUNK_E;
-    double *tab = (double *)(sGk + BA_CHUNK_E + 8); /* [Ncf][27] */
-    for (int i = tid; i < w.Ncf * 27; i += BA_T) tab[i] = 0.0;
-    for (int ch = ch0; ch < ch1; ch++) {
-        const int32_t *cd = I + w.ch_desc + ch * BA_CH_DESC;
-        const int e0 = cd[0], ne = cd[1] - cd[0], p0 = cd[2], npnt = cd[3] - cd[2], cg0 = cd[6], ncg = cd[7] - cd[6], g0 = cd[10], ng = cd[11];
-        if (tid < ng) sG[tid] = I[w.cg_edge + g0 + tid];
-        if (tid < ncg) sGs[tid] = I[w.cg_slot + cg0 + tid];
-        if (tid <= ncg) sGk[tid] = I[w.cg_start + cg0 + tid] - g0;
-        if (tid < ne) {
-            const int e = e0 + tid;
-            const uint8_t f = B[w.flags + e];
-            const int c = I[w.cam + e], p = I[w.pt + e];
-            const double er0 = D[w.err + (int64_t)e * 2], er1 = D[w.err + (int64_t)e * 2 + 1], info = D[w.info + e];
-            const double *pose = D + w.poses + (int64_t)c * 7;
-            const double *X = D + w.pts + (int64_t)p * 3;
-            double R[9], pc[3], Ji[6], Jj[12];
-            quat_to_R(pose, R);
-            pc[0] = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + pose[4];
-            pc[1] = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + pose[5];
-            pc[2] = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + pose[6];
-            jacobians(pose, pc, w.fx, w.fy, Ji, Jj);
-            double wgt = info, r0 = -info * er0, r1 = -info * er1;
-            if (f & 2) {
-                const double rw = huber_w((er0 * er0 + er1 * er1) * info, w.delta);
-                wgt *= rw;
-                r0 *= rw;
-                r1 *= rw;
-            }
-            if (!(f & 1)) wgt = r0 = r1 = 0.0; /* switched off: contributes nothing */
-            const double iz = 1.0 / pc[2];
-            double2 *We = (double2 *)(D + w.W + (int64_t)e * 4);
-            We[0] = double2{pc[0] * iz, pc[1] * iz};
-            We[1] = double2{iz, wgt};
-            double *j = sJ + tid * 15;
-#pragma unroll
-            for (int i = 0; i < 12; i++) j[i] = Jj[i];
-            j[12] = wgt;
-            j[13] = r0;
-            j[14] = r1;
-            double *hh = sH + tid * 9;
-            int q = 0;
-#pragma unroll
-            for (int a = 0; a < 3; a++)
-#pragma unroll
-                for (int bb = a; bb < 3; bb++) hh[q++] = wgt * (Ji[a] * Ji[bb] + Ji[3 + a] * Ji[3 + bb]);
-#pragma unroll
-            for (int a = 0; a < 3; a++) hh[6 + a] = Ji[a] * r0 + Ji[3 + a] * r1;
-        }
-        __syncthreads();
-        if (tid < npnt) { /* B1 */
-            const int p = p0 + tid, k0 = I[w.pt_start + p] - e0, k1 = I[w.pt_start + p + 1] - e0;
-            double h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-            for (int k = k0; k < k1; k++)
-#pragma unroll
-                for (int i = 0; i < 9; i++) h[i] += sH[k * 9 + i];
-            double *Hd = D + w.Hll + (int64_t)p * 9;
-            Hd[0] = h[0];
-            Hd[1] = h[1];
-            Hd[2] = h[2];
-            Hd[3] = h[1];
-            Hd[4] = h[3];
-            Hd[5] = h[4];
-            Hd[6] = h[2];
-            Hd[7] = h[4];
-            Hd[8] = h[5];
-            D[w.bl + (int64_t)p * 3] = h[6];
-            D[w.bl + (int64_t)p * 3 + 1] = h[7];
-            D[w.bl + (int64_t)p * 3 + 2] = h[8];
-        }
-        for (int id = tid; id < ncg * 27; id += BA_T) { /* B2 */
-            const int u = id / 27, q = id - u * 27;
-            const int sl = sGs[u], k0 = sGk[u], k1 = sGk[u + 1];
-            int a = 0, bb = 0;
-            if (q < 21) { /* q-th pair (a, bb) of the upper triangle, row-major */
-                int rem = q;
-                while (rem >= 6 - a) {
-                    rem -= 6 - a;
-                    a++;
-                }
-                bb = a + rem;
-            } else {
-                a = q - 21;
-            }
-            double v = 0.0;
-            for (int k = k0; k < k1; k++) {
-                const double *j = sJ + sG[k] * 15;
-                v += q < 21 ? j[12] * (j[a] * j[bb] + j[6 + a] * j[6 + bb]) : j[a] * j[13] + j[6 + a] * j[14];
-            }
-            tab[sl * 27 + q] += v;
-        }
-        __syncthreads();
-    }
-    double *Hp = D + w.Hp + (int64_t)part * w.Ncf * 27;
-    for (int i = tid; i < w.Ncf * 27; i += BA_T) Hp[i] = tab[i];
-}
-__global__ __launch_bounds__(BA_PH_T) void k_ba_ph_build_sum(BABufs bufs, int parts) {
-    BA_PH_WINDOW
-    if (ph != 0.0) return;
-    for (int i = threadIdx.x; i < w.Ncf * 27; i += BA_PH_T) {
-        double v = 0.0;
-        for (int pz = 0; pz < parts; pz++) v += D[w.Hp + (int64_t)pz * w.Ncf * 27 + i];
-        const int sl = i / 27, q = i - sl * 27;
-        if (q >= 21) {
-            D[w.bp + (int64_t)sl * 6 + (q - 21)] = v;
-        } else {
-            int a = 0, rem = q;
-            while (rem >= 6 - a) {
-                rem -= 6 - a;
-                a++;
-            }
-            const int bb = a + rem;
-            D[w.Hpp + (int64_t)sl * 36 + a * 6 + bb] = v;
-            D[w.Hpp + (int64_t)sl * 36 + bb * 6 + a] = v;
-        }
-    }
-    for (int c = threadIdx.x; c < w.Nc; c += BA_PH_T) { /* the cameras' rotations, for the consumers of the edge records */
-        double Rm[9];
-        quat_to_R(D + w.poses + (int64_t)c * 7, Rm);
-#pragma unroll
-        for (int i = 0; i < 9; i++) D[w.Rc + (int64_t)c * 9 + i] = Rm[i];
-    }
-}
 /* single workgroup per window: the current chi2 from its partial sums, computeLambdaInit on the first iteration of a
    round, trial counter */
 __global__ __launch_bounds__(BA_T) void k_ba_ph_prep(BABufs bufs) {
@@ -2435,7 +2287,7 @@ static int64_t BAWin::*const kScratchFields[] = {&BAWin::poses_t, &BAWin::pts_t,
                                                  &BAWin::tv,      &BAWin::Hpp,   &BAWin::bp,  &BAWin::Hll,   &BAWin::bl,
                                                  &BAWin::Dinv,    &BAWin::S,     &BAWin::g,   &BAWin::Minv,  &BAWin::x,
                                                  &BAWin::xl,      &BAWin::A,     &BAWin::Linv, &BAWin::gred,  &BAWin::pcgv,
-                                                 &BAWin::S2,      &BAWin::g2,    &BAWin::Rc,   &BAWin::Hp};
+                                                 &BAWin::S2,      &BAWin::g2,    &BAWin::Rc};
 #define BA_CHOL_LDS_BYTES (128 * 1024) /* dynamic LDS the blocked Cholesky may take beside the static 25 KB */
 
 /* Lay one problem out in the host staging vectors; returns an error code.  `team`: the window will be spread over
@@ -2704,7 +2556,6 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hO, std::vecto
     w.S = allocS((size_t)nnzb * 36);
     w.g = allocS((size_t)Ncf * 6);
     w.Rc = allocS((size_t)Nc * 9);
-    w.Hp = chunked ? allocS((size_t)BA_BUILD_PARTS * Ncf * 27) : 0;
     w.S2 = chunked ? allocS((size_t)nnzb * 36) : w.S; /* (never read when the window is not chunked) */
     w.g2 = chunked ? allocS((size_t)Ncf * 6) : w.g;
     w.Minv = allocS((size_t)Ncf * 36);
@@ -3161,15 +3012,6 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
         static PerDeviceLdsLimit lim_schur, lim_chol, lim_fin;
         static const int schur_skip = getenv("ORBSLAM_AMD_BA_SCHUR_SKIP") ? atoi(getenv("ORBSLAM_AMD_BA_SCHUR_SKIP")) : 0; /* timing experiments (results invalid) */
         BCHK(lim_schur.ensure((const void *)k_ba_ph_schur2, (size_t)BA_CHUNK_DOUBLES * 8));
-        /* buildSystem in one pass over the edges when every window's Hpp table fits LDS (ORBSLAM_AMD_BA_BUILD2: the point
-           pass and the camera pass as two kernels) */
-        int maxNcf = 0;
-        for (int i = 0; i < nwin; i++) maxNcf = std::max(maxNcf, J.wins[i].Ncf);
-        static const bool build2 = getenv("ORBSLAM_AMD_BA_BUILD2") != nullptr;
-        const bool fused_build = !build2 && maxNcf <= BA_BUILD_MAX_NCF;
-        const size_t build_doubles = (size_t)BA_CHUNK_E * 24 + (3 * (size_t)BA_CHUNK_E + 8) / 2 + 1 + (size_t)maxNcf * 27;
-        static PerDeviceLdsLimit lim_build;
-        if (fused_build) BCHK(lim_build.ensure((const void *)k_ba_ph_build, build_doubles * 8));
         BCHK(lim_chol.ensure((const void *)k_ba_ph_chol, chol_doubles * 8));
         const size_t fin_doubles = std::max<size_t>(chol_doubles, 2 * (size_t)BA_CHUNK_DOUBLES);
         BCHK(lim_fin.ensure((const void *)k_ba_ph_finish, fin_doubles * 8));
@@ -3213,16 +3055,8 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
             for (int t = 0; t < trials; t++, trial_seq++) {
                 const dim3 gE(nwin, partsE), gP(nwin, partsP), gC(nwin, partsC), tb(BA_PH_T);
                 if ((rc = timed(0, [&] { hipLaunchKernelGGL(k_ba_ph_chi2, gE, tb, 0, ks, bufs); }))) return rc;
-                if (fused_build) {
-                    if ((rc = timed(1, [&] {
-                             hipLaunchKernelGGL(k_ba_ph_build, dim3(nwin, BA_BUILD_PARTS), dim3(BA_T), build_doubles * 8, ks, bufs);
-                             hipLaunchKernelGGL(k_ba_ph_build_sum, dim3(nwin), tb, 0, ks, bufs, BA_BUILD_PARTS);
-                         })))
-                        return rc;
-                } else {
-                    if ((rc = timed(1, [&] { hipLaunchKernelGGL(k_ba_ph_hll, gP, tb, 0, ks, bufs); }))) return rc;
-                    if ((rc = timed(2, [&] { hipLaunchKernelGGL(k_ba_ph_hpp, gC, tb, 0, ks, bufs); }))) return rc;
-                }
+                if ((rc = timed(1, [&] { hipLaunchKernelGGL(k_ba_ph_hll, gP, tb, 0, ks, bufs); }))) return rc;
+                if ((rc = timed(2, [&] { hipLaunchKernelGGL(k_ba_ph_hpp, gC, tb, 0, ks, bufs); }))) return rc;
                 if ((rc = timed(3, [&] {
                          hipLaunchKernelGGL(k_ba_ph_prep, dim3(nwin), dim3(BA_T), 0, ks, bufs);
                          hipLaunchKernelGGL(k_ba_ph_dinv, gP, tb, 0, ks, bufs);
