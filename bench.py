@@ -96,6 +96,25 @@ def cpu_baseline(n_frames):
     return one, allc
 
 
+def tracking_loop(n_frames):
+    """BASELINE configs[4] in the shape this repo can give it (orbslam_in_practice_amd/sequence.py): ONE stream through
+    extract -> SearchByProjection -> PoseOptimization per frame and a local BA per keyframe, the calls chained the way
+    Tracking / LocalMapping chain them, host-pointer API, Python glue included; ATE against the synthetic ground truth.
+    (The same loop on the CPU oracle -- identical matches and trajectory -- is tests/test_gpu_sequence.py's business.)"""
+    from orbslam_in_practice_amd import sequence as sq
+    frames, gt, K, _ = sq.make_plane_sequence(5, n_frames)
+    be = sq.GpuBackend(NFEATURES, frames.shape[2], frames.shape[1])
+    sq.run_sequence(be, frames[:6], K, gt[0])  # warm-up
+    t0 = time.perf_counter()
+    r = sq.run_sequence(be, frames, K, gt[0])
+    dt = time.perf_counter() - t0
+    be.close()
+    return {"value": round(n_frames / dt, 1), "unit": "frames/s", "ate_rmse_m": round(sq.ate_rmse(r["poses"], gt), 5),
+            "local_ba_runs": int(r["ba_runs"]), "map_points": int(r["n_points"]), "mean_matches": round(float(r["n_matches"][1:].mean()), 1),
+            "workload": "%d synthetic frames %dx%d of a textured plane, %d features, keyframe every 4 frames, local BA over 5 "
+                        "keyframes; one stream, one frame at a time" % (n_frames, frames.shape[2], frames.shape[1], NFEATURES)}
+
+
 def ba_algorithmic_bytes(w, iterations, lin_solves):
     """SURVEY.md 8(d), f64: bytes one window moves over its whole solve -- linearise/build once per LM iteration;
     Schur complement, back-substitution and update + re-evaluation once per linear solve (LM trial).  No PCG term:
@@ -209,7 +228,8 @@ def main():
     ap.add_argument("--split", type=int, default=2, help="1..4 launch lanes: equal parts of a batch on separate stream pairs")
     ap.add_argument("--ba-windows", type=int, default=256, help="local-BA windows per GPU per batch (0 = skip)")
     ap.add_argument("--ba-size", default="100x5000", help="keyframes x points of a window (configs[2] = 50x2000)")
-    ap.add_argument("--ba-reps", type=int, default=6, help="batches in the timed BA stream")
+    ap.add_argument("--ba-reps", type=int, default=12, help="batches in the timed BA stream")
+    ap.add_argument("--sequence-frames", type=int, default=40, help="frames of the one-stream tracking loop (rank 0, N=1; 0 = skip)")
     args = ap.parse_args()
     W, H = (int(v) for v in args.size.lower().split("x"))
     NFEATURES = args.nfeatures
@@ -435,6 +455,8 @@ def main():
             out["cpu_baseline"], out["cpu_baseline_all_cores"] = cpu_baseline(args.cpu_frames)
         if local_ba is not None:
             out["local_ba"] = local_ba
+        if world == 1 and args.sequence_frames > 0:
+            out["tracking_loop"] = tracking_loop(args.sequence_frames)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
