@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised BA parity sweep against the CPU oracle: random window sizes, fixed-camera sets, outlier fractions,
 schedules, robust on/off, shuffled camera order; estimates within 1e-5 relative, outlier labels equal.
-Usage: python tests/fuzz_ba.py [n_configs] [seed]"""
+Usage: python tests/fuzz_ba.py [n_configs] [seed]   |   python tests/fuzz_ba.py batch [n_batches] [seed]"""
 import os
 import sys
 
@@ -77,7 +77,53 @@ def run(n_cfg=24, seed=3):
     return 1 if bad else 0
 
 
+def run_batches(n_batches=2, seed=11, sample=3):
+    """batches of more than 128 random windows: the phase-kernel path of the solver (an LM trial = a sequence of kernels
+    over all windows).  Every `sample`-th window is checked against the oracle."""
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for b in range(n_batches):
+        nwin = int(rng.integers(129, 170))
+        rounds = [(5, 10), (10,), (3, 3, 3)][int(rng.integers(0, 3))]
+        robust = bool(rng.integers(0, 4) > 0)
+        ws = []
+        for i in range(nwin):
+            nc = int(rng.integers(3, 36))
+            npt = int(rng.integers(30, 40 * nc + 40))
+            w = synth.make_ba_window(int(rng.integers(1 << 30)), nc, npt, outlier_frac=float(rng.choice([0.0, 0.05, 0.15])))
+            nfix = int(rng.integers(1, max(2, nc // 3)))
+            w["fixed"][:] = 0
+            w["fixed"][rng.permutation(nc)[:nfix]] = 1
+            ws.append(w)
+        opt = oa.Optimizer(max_cams=40, max_points=2048, max_obs=40000, max_batch=nwin)
+        opt.set_profiling(True)
+        got = opt.solve_batch(ws, rounds, robust=robust)
+        team = opt.iteration_ms()[2]
+        opt.close()
+        nb = 0
+        for i in range(0, nwin, sample):
+            w, g = ws[i], got[i]
+            ref = orc.ba_solve(w, rounds=rounds, robust=robust)
+            same_its = g["iterations"] == ref["iterations"] or \
+                abs(g["chi2_final"] - ref["chi2_final"]) <= 1e-9 * max(ref["chi2_final"], 1e-30)
+            ok = (same_its and np.array_equal(g["outlier"], ref["outlier"]) and
+                  rel(g["points"], ref["points"]) < 1e-5 and rel(g["poses"][:, 4:], ref["poses"][:, 4:]) < 1e-5 and
+                  abs(g["chi2_final"] - ref["chi2_final"]) <= 1e-6 * ref["chi2_final"] + 1e-18 * ref["chi2_initial"])  # (a noise-free window ends at 1e-27)
+            if not ok:
+                nb += 1
+                print("   batch %d window %d: cams %d points %d its %d/%d solves %d/%d flags differ %d rel(points) %.1e chi2 %.9e / %.9e" % (
+                    b, i, len(w["poses"]), len(w["points"]), g["iterations"], ref["iterations"], g["lin_solves"], ref["lin_solves"],
+                    int(np.count_nonzero(g["outlier"] != ref["outlier"])), rel(g["points"], ref["points"]), g["chi2_final"], ref["chi2_final"]))
+        print("batch %d: %d windows, rounds %s robust %d, %s: %d mismatches in %d checked" % (
+            b, nwin, rounds, robust, "phase kernels" if team == 0 else "fused kernel (team %d)" % team, nb, len(range(0, nwin, sample))), flush=True)
+        bad += nb
+    print("FUZZ-BA-BATCH %s: %d mismatches" % ("FAILED" if bad else "OK", bad))
+    return 1 if bad else 0
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "batch":  # python tests/fuzz_ba.py batch [n_batches] [seed]
+        return run_batches(int(sys.argv[2]) if len(sys.argv) > 2 else 4, int(sys.argv[3]) if len(sys.argv) > 3 else 11, 1)
     return run(int(sys.argv[1]) if len(sys.argv) > 1 else 24, int(sys.argv[2]) if len(sys.argv) > 2 else 3)
 
 

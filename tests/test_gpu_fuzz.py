@@ -25,3 +25,8 @@ def test_front_end_fuzz(seed, wild):
 
 def test_ba_fuzz():
     assert _load("fuzz_ba").run(8, 20263) == 0
+
+
+def test_ba_batch_fuzz():
+    """a batch of 129+ random windows (the phase-kernel path), a third of them against the oracle"""
+    assert _load("fuzz_ba").run_batches(1, 20264, 3) == 0
