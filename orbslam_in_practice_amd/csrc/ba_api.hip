@@ -521,11 +521,13 @@ __device__ __noinline__ bool ba_chol_solve(const BAWin &w, double *D, const int3
        indices are static.  The textbook right-looking loop (a[i][k] -= l[i][j] * l[k][j] for j < k <= i), with one
        reciprocal square root per column instead of a division per entry; a third of the time of the LDS version it
        replaces (16 columns x 3 LDS round trips per column there).  The tile comes from memory, or from `sd` when this
-       wavefront has just updated it (look-ahead, below); only its inverse leaves the wavefront (the substitutions and
-       the panel use L11^-1, never L11 itself). */
+       wavefront has just updated it (look-ahead, below); only its inverse is needed outside (the substitutions and the
+       panel use L11^-1, never L11 itself). */
     auto factor_diag = [&](int kb, bool from_lds) {
         const int rl = lane & 15;
         double a[16];
+        unsigned long long tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0; /* (profile mode: time split of the tile) */
+        if (debug) tq0 = __builtin_amdgcn_s_memrealtime();
         if (from_lds) {
 #pragma unroll
             for (int k = 0; k < 16; k++) a[k] = sd[rl * CH_LD + k];
@@ -534,6 +536,7 @@ __device__ __noinline__ bool ba_chol_solve(const BAWin &w, double *D, const int3
 #pragma unroll
             for (int k = 0; k < 16; k++) a[k] = Ar[k];
         }
+        if (debug) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tq1 = __builtin_amdgcn_s_memrealtime(); }
         bool bad = false;
         double inv[16]; /* 1 / l[j][j]: the column scaling and the inverse below multiply by it */
 #pragma unroll
@@ -560,6 +563,7 @@ __device__ __noinline__ bool ba_chol_solve(const BAWin &w, double *D, const int3
                 a[k] -= a[j] * lkj;
             }
         }
+        if (debug) { asm volatile("" : "+v"(a[15])); tq2 = __builtin_amdgcn_s_memrealtime(); }
         /* column rl of L^-1 by forward substitution: x[i] = (delta - sum_{k<i} l[i][k] x[k]) / l[i][i] */
         double x[16];
 #pragma unroll
@@ -570,7 +574,20 @@ __device__ __noinline__ bool ba_chol_solve(const BAWin &w, double *D, const int3
                 if (k < i) v -= lane_bcast(a[k], i) * x[k];
             x[i] = (i >= rl) ? v * inv[i] : 0.0;
         }
+        if (debug) { asm volatile("" : "+v"(x[15])); tq3 = __builtin_amdgcn_s_memrealtime(); }
+        if (debug && lane == 0) {
+            D[w.st + ST_T0 + 17] += (double)(tq1 - tq0);
+            D[w.st + ST_T0 + 14] += (double)(tq2 - tq1);
+            D[w.st + ST_T0 + 15] += (double)(tq3 - tq2);
+        }
         if (lane < 16) {
+            if (!AHEAD) { /* L11 over the tile in memory.  NOTHING reads it (the substitutions and the panel use L11^-1), yet with
+                             256 windows in flight the kernel takes 8.7 ms per batch with this store and 10.3 without -- measured
+                             both ways on one device, not understood; kept where it pays */
+                double *Ar = A + (int64_t)(kb * 16 + rl) * np + kb * 16;
+#pragma unroll
+                for (int c = 0; c < 16; c++) Ar[c] = (c <= rl) ? a[c] : 0.0;
+            }
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 sl[i * CH_LD + rl] = x[i];           /* (x[i] is 0 above the diagonal) */
