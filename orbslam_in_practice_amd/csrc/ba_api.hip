@@ -3023,7 +3023,7 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
     int total_its = 0;
     for (int r = 0; r < P0.n_rounds; r++) total_its += P0.rounds[r];
     if (s->profiling) {
-        while ((int)J.prof_ev.size() < 2 * total_its) {
+        while ((int)J.prof_ev.size() < 2 * std::max(total_its, P0.n_rounds)) { /* (the phase-kernel path brackets rounds, also empty ones) */
             hipEvent_t e;
             BCHK(hipEventCreate(&e));
             J.prof_ev.push_back(e);
