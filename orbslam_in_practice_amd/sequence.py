@@ -12,9 +12,9 @@ What the out-of-scope callers would do is replaced by scene knowledge: the scene
 becomes a map point by intersecting its viewing ray with the plane (instead of the Initializer's / LocalMapping's
 triangulation), the first frame's pose is given, and a frame predicts its pose with the constant-velocity model.
 
-`backend` is either the product (`GpuBackend`: the HIP path through the C-ABI) or the checker (`OracleBackend`: the
-CPU restatement under oracle/ -- only tests/ and tools/ may construct that one).  Same loop, same arithmetic around
-the calls: the two trajectories are compared by tests/test_gpu_sequence.py.
+`backend` is the product (`GpuBackend`: the HIP path through the C-ABI) -- or, in tests/ only, the checker
+(tests/sequence_oracle.py: the same five calls on the CPU restatement under oracle/).  Same loop, same arithmetic
+around the calls: the two trajectories are compared by tests/test_gpu_sequence.py.
 """
 import numpy as np
 
@@ -96,7 +96,7 @@ def backproject_to_plane(pose, K, xy):
     return C[None, :] + lam[:, None] * r
 
 
-# ---- the two backends ----------------------------------------------------------------------------------------------
+# ---- the backend ---------------------------------------------------------------------------------------------------
 class GpuBackend:
     """the product: HIP kernels through the C-ABI (fails loudly when liborbslam_amd.so is missing)"""
     name = "gpu"
@@ -130,37 +130,6 @@ class GpuBackend:
         self.opt.close()
         self.matcher.close()
         self.ext.close()
-
-
-class OracleBackend:
-    """the checker: oracle/ (CPU restatement of the reference's algorithm)"""
-    name = "oracle"
-
-    def __init__(self, nfeatures, w, h):
-        from oracle import oracle as orc
-        self.orc = orc
-        self.ext = orc.OrbOracle(nfeatures, 1.2, 8, 20, 7)
-        self.bounds = (0.0, float(w), 0.0, float(h))
-        t = self.ext.tables()
-        self.scale_factors = np.asarray(t["scale"], np.float32)
-        self.inv_sigma2 = np.asarray(t["inv_sigma2"], np.float64)
-
-    def extract(self, img):
-        return self.ext.extract(img)
-
-    def search_by_projection(self, cur, last, last_flags, last_xw, R, t, K, th):
-        n, m, _ = self.orc.search_by_projection(cur[0], cur[1], last[0], last[1], self.bounds, last_flags, last_xw, R, t, K[0], K[1], K[2], K[3],
-                                                self.scale_factors, np.zeros(len(cur[0]), np.uint8), th)
-        return n, m
-
-    def pose_optimization(self, pose, xw, obs, inv_sigma2, K):
-        return self.orc.pose_optimization(pose, xw, obs, inv_sigma2, *K)
-
-    def local_ba(self, window):
-        return self.orc.ba_solve(window, rounds=(5, 10))
-
-    def close(self):
-        pass
 
 
 # ---- the loop ------------------------------------------------------------------------------------------------------
