@@ -51,6 +51,14 @@
 #define BA_CHUNK_C 2560 /* ... and its contribution list (packed local edges + point, ints) */
 #define BA_CHUNK_B 256  /* ... and the blocks it touches (id, list start) */
 #define BA_CH_DESC 16   /* ints per chunk descriptor */
+/* an entry of a chunk's block list: block id, plus two flags for the two-part Schur pass of the phase-kernel path --
+   FIRST: no earlier chunk of the same part touches this block, so the part does not read the block but starts it (at
+   Hpp + lambda I for a diagonal block of part 0, at zero otherwise) -- which is what spares that path the
+   initialisation pass over S and the zero fill of S2 (360 MB of 600 per trial and 256 windows); DIAG: a diagonal block */
+#define BA_BLK_FIRST (1 << 30)
+#define BA_BLK_DIAG (1 << 29)
+#define BA_BLK_MASK ((1 << 29) - 1)
+#define BA_SCHUR_PARTS 2
 #define BA_CHUNK_DOUBLES (BA_CHUNK_E * 18 + BA_CHUNK_P * 12 + BA_CHUNK_E / 2 + BA_CHUNK_C / 2 + BA_CHUNK_B + BA_CHUNK_E / 2 + 32)
 
 static OrbErrSlot b_err; /* forwards to orb_last_error() */
@@ -82,6 +90,7 @@ struct BAWin {
        the free cameras it touches with their local edge lists; nchunks == 0: list path only */
     int nchunks, pad_;
     int64_t ch_desc, cb_blk, cb_start, cb_con, cg_slot, cg_start, cg_edge;
+    int64_t blk_touch;         /* ints, per block: bit p set = part p of the two-part Schur pass touches (and starts) the block */
     int64_t gbar;              /* ints: two arrival counters of the window's workgroup team (alternating per launch) */
     int64_t gred;              /* doubles (scratch): 2 slots x 2 values x BA_GMAX partial sums of the team */
     int64_t pcgv;              /* doubles (scratch): x, r, z, p, Ap of a PCG whose vectors exceed the LDS arrays (n > BA_MAX_N) */
@@ -481,7 +490,7 @@ __device__ __forceinline__ void ba_chol_assemble(const BAWin &w, double *D, cons
     for (int i = gtid; i < w.nnzb * 36; i += gthreads) {
         const int bk = i / 36, e = i - bk * 36;
         const int br = I[w.blk_rowid + bk], bc = I[w.blk_col + bk];
-        if (bc >= br) A[(int64_t)(bc * 6 + e % 6) * np + br * 6 + e / 6] = TWO ? D[w.S + i] + D[w.S2 + i] : D[w.S + i];
+        if (bc >= br) A[(int64_t)(bc * 6 + e % 6) * np + br * 6 + e / 6] = (TWO && (I[w.blk_touch + bk] & 2)) ? D[w.S + i] + D[w.S2 + i] : D[w.S + i];
     }
     for (int i = n + gtid; i < np; i += gthreads) A[(int64_t)i * np + i] = 1.0; /* identity padding */
 }
@@ -872,7 +881,7 @@ __device__ __noinline__ void ba_schur_chunked(const BAWin &w, double *D, const i
         SCH_STAMP(1)
         /* blocks: group g takes blocks g, g + 32, ... of the chunk's list (sorted heaviest first on the host) */
         for (int u = grp; u < ncb; u += BA_T / 16) {
-            const int bk = sB[u], k0 = sBS[u], k1 = sBS[u + 1];
+            const int bk = sB[u] & BA_BLK_MASK, k0 = sBS[u], k1 = sBS[u + 1]; /* (the flags serve the two-part pass) */
             /* lanes 0..11 of the group own 3 entries of the 6 x 6 block each for the update; requested now, used last */
             double *Sb = D + w.S + (int64_t)bk * 36 + (l16 < 12 ? l16 : 0) * 3;
             const double sb0 = Sb[0], sb1 = Sb[1], sb2 = Sb[2];
@@ -1287,6 +1296,8 @@ __device__ __forceinline__ double ba_phase_lambda0(const BAWin &w, const double 
 /* Dinv = (Hll + lambda I)^-1 and tv = Dinv bl (thread per point); S := Hpp + lambda I on its diagonal blocks, g := bp.
    Y = W Dinv is never stored: the Schur products form it in registers from W and Dinv (54 FMAs per contribution against
    a 144-byte record written, read back ~6 times and mostly missing every cache when 256 windows run at once). */
+/* PARTS: the two-part Schur pass starts the blocks it touches itself (BA_BLK_FIRST); only the others are written here */
+template <bool PARTS = false>
 __device__ __forceinline__ void ba_phase_dinv(const BAWin &w, double *D, const int32_t *I, double lambda, int gtid, int gthreads) {
     for (int p = gtid; p < w.Np; p += gthreads) {
         double Dm[9];
@@ -1315,7 +1326,9 @@ __device__ __forceinline__ void ba_phase_dinv(const BAWin &w, double *D, const i
        subtracted from them below (disjoint writers, no barrier needed between the two loops) */
     for (int i = gtid; i < w.nnzb * 36; i += gthreads) {
         const int bk = i / 36, e = i - bk * 36;
+        if (PARTS && (I[w.blk_touch + bk] & 1)) continue;
         const int sl = I[w.blk_rowid + bk];
+        if (PARTS && I[w.blk_col + bk] < sl) continue; /* (the Cholesky assembly reads the blocks on or above the diagonal only) */
         double v = 0.0;
         if (I[w.blk_col + bk] == sl) {
             v = D[w.Hpp + (int64_t)sl * 36 + e];
@@ -1373,9 +1386,9 @@ __device__ __forceinline__ double ba_phase_backsub(const BAWin &w, double *D, co
     }
     return scale_loc;
 }
-/* the second accumulators of the two-part Schur pass start at zero */
+/* the second accumulator of g starts at zero (S2 needs no fill: part 1 starts the blocks it touches, the assembly
+   reads no others) */
 __device__ __forceinline__ void ba_phase_zero2(const BAWin &w, double *D, int gtid, int gthreads) {
-    for (int i = gtid; i < w.nnzb * 36; i += gthreads) D[w.S2 + i] = 0.0;
     for (int i = gtid; i < w.Ncf * 6; i += gthreads) D[w.g2 + i] = 0.0;
 }
 /* accepted trial: it becomes the estimate */
@@ -1788,7 +1801,7 @@ template <class SH> __device__ __forceinline__ void ba_ph_dinv(const BAWin &w, d
         }
         if (build) st[ST_QMAX] = 0.0;
     }
-    ba_phase_dinv(w, D, I, lambda, threadIdx.x, BA_T);
+    ba_phase_dinv<true>(w, D, I, lambda, threadIdx.x, BA_T);
 }
 __device__ __forceinline__ void ba_ph_chol(const BAWin &w, double *D, const int32_t *I, double *dyn, double *bad_flag) {
     double *st = D + w.st;
@@ -1974,7 +1987,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_ph_prep(BABufs bufs) {
 __global__ __launch_bounds__(BA_PH_T) void k_ba_ph_dinv(BABufs bufs) {
     BA_PH_WINDOW
     if (ph == 2.0) return;
-    ba_phase_dinv(w, D, I, D[w.st + ST_LAMBDA], blockIdx.y * BA_PH_T + threadIdx.x, gridDim.y * BA_PH_T);
+    ba_phase_dinv<true>(w, D, I, D[w.st + ST_LAMBDA], blockIdx.y * BA_PH_T + threadIdx.x, gridDim.y * BA_PH_T);
     ba_phase_zero2(w, D, blockIdx.y * BA_PH_T + threadIdx.x, gridDim.y * BA_PH_T);
 }
 /* The Schur pass of the phase-kernel path: the window's point chunks are split over two groups of 256 threads,
@@ -1996,6 +2009,7 @@ __device__ __forceinline__ void ba_schur_part(const BAWin &w, double *D, const i
 #pragma clang fp contract(fast)
     const int ch0 = (int)((int64_t)w.nchunks * part / nparts), ch1 = (int)((int64_t)w.nchunks * (part + 1) / nparts);
     const int64_t So = part == 0 ? w.S : w.S2, go = part == 0 ? w.g : w.g2;
+    const double lambda = D[w.st + ST_LAMBDA];
     double *sW = tile, *sD = sW + BA_CHUNK_E * 18, *sT = sD + BA_CHUNK_P * 9;
     int32_t *sP = (int32_t *)(sT + BA_CHUNK_P * 3);
     int32_t *sC = sP + BA_CHUNK_E;
@@ -2073,14 +2087,34 @@ __device__ __forceinline__ void ba_schur_part(const BAWin &w, double *D, const i
         __syncthreads();
         /* blocks: group g takes blocks g, g + 16, ... of the chunk's list (sorted heaviest first on the host); the
            block's current value is fetched one pair ahead */
+        /* current value of entries 3 * l16 .. of a block: from memory, or -- FIRST touch by this part -- what the block
+           starts at: Hpp + lambda I for a diagonal block of part 0, zero otherwise */
+        auto block_value = [&](int raw, double *&ptr, double &v0, double &v1, double &v2) {
+            const int bk = raw & BA_BLK_MASK, e3 = (l16 < 12 ? l16 : 0) * 3;
+            ptr = D + So + (int64_t)bk * 36 + e3;
+            if (!(raw & BA_BLK_FIRST)) {
+                v0 = ptr[0];
+                v1 = ptr[1];
+                v2 = ptr[2];
+            } else if (part == 0 && (raw & BA_BLK_DIAG)) {
+                const double *Hd = D + w.Hpp + (int64_t)I[w.blk_rowid + bk] * 36 + e3;
+                v0 = Hd[0] + (e3 % 7 == 0 ? lambda : 0.0);
+                v1 = Hd[1] + ((e3 + 1) % 7 == 0 ? lambda : 0.0);
+                v2 = Hd[2] + ((e3 + 2) % 7 == 0 ? lambda : 0.0);
+            } else {
+                v0 = v1 = v2 = 0.0;
+            }
+        };
         int u = (skip & 16) ? ncb : grp;
-        double *Sb = D + So + (int64_t)(u < ncb ? sB[u] : 0) * 36 + (l16 < 12 ? l16 : 0) * 3;
-        double sb0 = Sb[0], sb1 = Sb[1], sb2 = Sb[2];
+        double *Sb = nullptr;
+        double sb0 = 0, sb1 = 0, sb2 = 0;
+        if (u < ncb) block_value(sB[u], Sb, sb0, sb1, sb2);
         for (; u < ncb; u += BA_SH_T / 16) {
             const int k0 = sBS[u], k1 = sBS[u + 1];
             const int un = u + BA_SH_T / 16;
-            double *Sn = D + So + (int64_t)(un < ncb ? sB[un] : sB[u]) * 36 + (l16 < 12 ? l16 : 0) * 3;
-            const double sn0 = Sn[0], sn1 = Sn[1], sn2 = Sn[2];
+            double *Sn = Sb;
+            double sn0 = 0, sn1 = 0, sn2 = 0;
+            if (un < ncb) block_value(sB[un], Sn, sn0, sn1, sn2);
             double acc[36];
 #pragma unroll
             for (int i = 0; i < 36; i++) acc[i] = 0.0;
@@ -2320,7 +2354,7 @@ static int64_t BAWin::*const kInDFields[] = {&BAWin::obs, &BAWin::info};
 static int64_t BAWin::*const kIntFields[] = {&BAWin::cam,     &BAWin::pt,      &BAWin::pt_start, &BAWin::cam_start,
                                              &BAWin::cam_edges, &BAWin::slot,  &BAWin::blk_row,  &BAWin::blk_col,
                                              &BAWin::blk_diag, &BAWin::blk_mirror, &BAWin::blk_upper, &BAWin::blk_rowid, &BAWin::con_start, &BAWin::con_e1, &BAWin::con_e2, &BAWin::ch_first, &BAWin::ch_last,
-                                             &BAWin::ch_desc, &BAWin::cb_blk, &BAWin::cb_start, &BAWin::cb_con, &BAWin::cg_slot, &BAWin::cg_start, &BAWin::cg_edge, &BAWin::gbar};
+                                             &BAWin::ch_desc, &BAWin::cb_blk, &BAWin::cb_start, &BAWin::cb_con, &BAWin::cg_slot, &BAWin::cg_start, &BAWin::cg_edge, &BAWin::gbar, &BAWin::blk_touch};
 static int64_t BAWin::*const kScratchFields[] = {&BAWin::poses_t, &BAWin::pts_t, &BAWin::err, &BAWin::err_t, &BAWin::W,
                                                  &BAWin::tv,      &BAWin::Hpp,   &BAWin::bp,  &BAWin::Hll,   &BAWin::bl,
                                                  &BAWin::Dinv,    &BAWin::S,     &BAWin::g,   &BAWin::Minv,  &BAWin::x,
@@ -2684,6 +2718,23 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hO, std::vecto
     w.con_e1 = putI(ce1);
     w.con_e2 = putI(ce2);
     w.nchunks = (int)chd.size() / BA_CH_DESC;
+    {
+        /* first-touch flags of the two-part Schur pass (part p = chunks [nchunks p / 2, nchunks (p + 1) / 2)) */
+        std::vector<int> touch(std::max(nnzb, 1), 0);
+        for (int part = 0; part < BA_SCHUR_PARTS; part++) {
+            const int c0 = (int)((int64_t)w.nchunks * part / BA_SCHUR_PARTS), c1 = (int)((int64_t)w.nchunks * (part + 1) / BA_SCHUR_PARTS);
+            for (int ch = c0; ch < c1; ch++)
+                for (int k = chd[(size_t)ch * BA_CH_DESC + 4]; k < chd[(size_t)ch * BA_CH_DESC + 5]; k++) {
+                    const int bk = cbb[k];
+                    if (bcol[bk] == hI[w.blk_rowid + bk]) cbb[k] |= BA_BLK_DIAG;
+                    if (!(touch[bk] & (1 << part))) {
+                        touch[bk] |= 1 << part;
+                        cbb[k] |= BA_BLK_FIRST;
+                    }
+                }
+        }
+        w.blk_touch = putI(touch);
+    }
     w.ch_desc = putI(chd);
     w.cb_blk = putI(cbb);
     w.cb_start = putI(cbs);
