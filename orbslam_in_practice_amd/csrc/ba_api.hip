@@ -3176,8 +3176,8 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
         if (phase_prof) {
             fprintf(stderr, "[ba] phase kernels, %d windows, ms: chi2 %.2f | Hll %.2f | Hpp+W %.2f | Dinv %.2f | Schur %.2f | Cholesky %.2f | backsub %.2f | trial %.2f | decide+accept %.2f | finish %.2f\n",
                     nwin, phase_ms[0], phase_ms[1], phase_ms[2], phase_ms[3], phase_ms[4], phase_ms[5], phase_ms[6], phase_ms[7], phase_ms[8], phase_ms[9]);
-            hipEventDestroy(pe0);
-            hipEventDestroy(pe1);
+            (void)hipEventDestroy(pe0);
+            (void)hipEventDestroy(pe1);
         }
     }
     for (int round = 0; round < P0.n_rounds && !halted && !split; round++) {

@@ -350,12 +350,15 @@ static int set_geometry(OrbExtractor *h, int w, int hgt) {
     if ((rc = grow(h->d_cells, h->cap_cells, std::max<size_t>(h->h_cells.size(), 1)))) return rc;
     if ((rc = grow(h->d_tab_i, h->cap_tab_i, std::max<size_t>(h->h_tab_i.size(), 1)))) return rc;
     if ((rc = grow(h->d_tab_c, h->cap_tab_c, std::max<size_t>(h->h_tab_c.size(), 2)))) return rc;
+    /* (on the handle's own stream: a synchronous hipMemcpy runs on the legacy stream, and ROCm 7.2 fails legacy-stream
+       operations -- or the capture -- while ANOTHER host thread's extractor captures its launch graph) */
     if (!h->h_cells.empty())
-        HIPCHK(hipMemcpy(h->d_cells, h->h_cells.data(), h->h_cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpyAsync(h->d_cells, h->h_cells.data(), h->h_cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice, h->stream));
     if (!h->h_tab_i.empty()) {
-        HIPCHK(hipMemcpy(h->d_tab_i, h->h_tab_i.data(), h->h_tab_i.size() * 4, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(h->d_tab_c, h->h_tab_c.data(), h->h_tab_c.size() * 2, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpyAsync(h->d_tab_i, h->h_tab_i.data(), h->h_tab_i.size() * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_tab_c, h->h_tab_c.data(), h->h_tab_c.size() * 2, hipMemcpyHostToDevice, h->stream));
     }
+    HIPCHK(hipStreamSynchronize(h->stream));
     h->buf.cells = h->d_cells;
     h->buf.tab_i = h->d_tab_i;
     h->buf.tab_c = h->d_tab_c;
@@ -454,7 +457,7 @@ extern "C" int orb_create(const OrbConfig *cfg, int max_w, int max_h, int max_ba
     }
     h->overlap = getenv("ORBSLAM_AMD_NO_OVERLAP") == nullptr;
     h->use_graph = getenv("ORBSLAM_AMD_NO_GRAPH") == nullptr;
-    if (orb_upload_constants() != hipSuccess) {
+    if (orb_upload_constants(h->device, h->stream) != hipSuccess) {
         g_err = "constant upload failed";
         return fail(ORB_E_HIP);
     }
@@ -692,9 +695,14 @@ extern "C" int orb_extract_batch(OrbExtractor *h, const uint8_t *const *imgs, in
         if (h->graph) (void)hipGraphDestroy(h->graph);
         h->graph_exec = nullptr;
         h->graph = nullptr;
-        HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        /* RELAXED capture mode: only this handle's (non-blocking) stream takes part in the capture, and its dependencies
+           are explicit events.  In thread-local mode ROCm 7.2 still fails calls of OTHER host threads while this one
+           captures (a second extractor's hipMemcpyAsync came back with "would make the legacy stream depend on a
+           capturing blocking stream", about once in ten runs of three extractors starting up on three threads). */
+        HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
         rc = enqueue();
         hipError_t ce = hipStreamEndCapture(h->stream, &h->graph);
+        if (rc || ce != hipSuccess) (void)hipGetLastError(); /* (the eager fallback below starts from a clean error state) */
         if (rc || ce != hipSuccess || hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0) != hipSuccess) {
             /* capture not possible here: fall back to eager launches for good (still the same kernels) */
             h->use_graph = false;
@@ -790,8 +798,11 @@ extern "C" int orb_download_candidates(OrbExtractor *h, int frame, int level, Or
     const LevelGeom &L = g.lv[level];
     std::vector<int32_t> cnt(std::max(L.n_cells, 1));
     if (L.n_cells)
-        HIPCHK(hipMemcpy(cnt.data(), h->buf.cell_cnt + (size_t)frame * g.total_cells + L.cell_base, (size_t)L.n_cells * 4,
-                         hipMemcpyDeviceToHost));
+    {
+        HIPCHK(hipMemcpyAsync(cnt.data(), h->buf.cell_cnt + (size_t)frame * g.total_cells + L.cell_base, (size_t)L.n_cells * 4,
+                              hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
     int n = 0;
     std::vector<uint32_t> keys;
     for (int c = 0; c < L.n_cells; c++) {
@@ -802,8 +813,9 @@ extern "C" int orb_download_candidates(OrbExtractor *h, int frame, int level, Or
         }
         if (cnt[c] == 0) continue;
         keys.resize(cnt[c]);
-        HIPCHK(hipMemcpy(keys.data(), h->buf.slab + (size_t)frame * g.slab_frame_count + cd.slab_off, (size_t)cnt[c] * 4,
-                         hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpyAsync(keys.data(), h->buf.slab + (size_t)frame * g.slab_frame_count + cd.slab_off, (size_t)cnt[c] * 4,
+                              hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
         for (int k = 0; k < cnt[c]; k++, n++) {
             if (out && n < cap) {
                 OrbKeyPoint kp;

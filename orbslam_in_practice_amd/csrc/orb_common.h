@@ -103,7 +103,7 @@ hipError_t launch_pyramid(const OrbGeom &g, const OrbBuffers &b, const uint8_t *
 hipError_t launch_blur(const OrbGeom &g, const OrbBuffers &b, int n_frames, hipStream_t st);
 hipError_t launch_fast(const OrbGeom &g, const OrbBuffers &b, int n_frames, hipStream_t st);
 hipError_t launch_quadtree(const OrbGeom &g, const OrbBuffers &b, int n_frames, hipStream_t st);
-hipError_t orb_upload_constants();
+hipError_t orb_upload_constants(int device, hipStream_t stream);
 hipError_t launch_describe(const OrbGeom &g, const OrbBuffers &b, int n_frames, OrbKeyPoint *d_kps,
                            uint8_t *d_desc, int cap, int32_t *d_counts, hipStream_t st);
 

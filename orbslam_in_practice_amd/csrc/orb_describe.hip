@@ -15,6 +15,7 @@
  *     ORC_TRIG_DET) and f32 mul/add without FMA contraction, then round-half-even (cvRound).
  */
 #include "orb_common.h"
+#include <mutex>
 
 __constant__ int8_t c_pattern[1024]; /* 256 x (x0,y0,x1,y1), reference src/ORBextractor.cpp:100-358 */
 static const int8_t h_pattern[1024] = {
@@ -184,9 +185,18 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeom g, const uint8_t *pyr,
     }
 }
 
-/* one-time (per device) upload of the sampling pattern; called from orb_create, never from a launch path */
-hipError_t orb_upload_constants() {
-    return hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), h_pattern, sizeof(h_pattern));
+/* upload of the sampling pattern, ONCE per device (the table never changes), on the caller's stream: called from
+   orb_create, never from a launch path.  Not hipMemcpyToSymbol: that one runs on the legacy stream, which ROCm 7.2
+   refuses while another host thread's extractor captures its launch graph. */
+hipError_t orb_upload_constants(int device, hipStream_t stream) {
+    static std::mutex mu;
+    static bool done[64] = {};
+    std::lock_guard<std::mutex> lock(mu);
+    if (device >= 0 && device < 64 && done[device]) return hipSuccess;
+    hipError_t e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_pattern), h_pattern, sizeof(h_pattern), 0, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e == hipSuccess && device >= 0 && device < 64) done[device] = true;
+    return e;
 }
 
 hipError_t launch_describe(const OrbGeom &g, const OrbBuffers &b, int n_frames, OrbKeyPoint *d_kps, uint8_t *d_desc,

@@ -26,6 +26,7 @@
 #define FT_LD 68 /* LDS row pitch */
 
 typedef short v2s __attribute__((ext_vector_type(2)));
+typedef unsigned short v2u __attribute__((ext_vector_type(2)));
 
 /* cornerScore of one pixel.  Both ring polarities ride in one packed register: element k holds
  * (d[k], -d[k]) with d = v - ring[k]; the max over the 16 nine-arcs of the arc minimum is then the "dark"
@@ -335,7 +336,7 @@ __device__ __forceinline__ uint32_t fast_score_pair_ld(const uint8_t *ca, int sa
  *           into the queue entry;
  *   pass C  ordered emission of the queue entries selected by the per-cell threshold fallback. */
 __global__ __launch_bounds__(64) void k_fast_cells_wave(OrbGeom g, const uint8_t *pyr, const CellDesc *cells, uint32_t *slab,
-                                                        int32_t *cell_cnt, int ld, int lh, int stop_after) {
+                                                        int32_t *cell_cnt, int ld, int lh, int stop_after, int fast_a0_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t fw_smem[];
     uint8_t *s_px = fw_smem;                             /* [lh][ld], column 0 <-> x = iniX & ~3 */
     uint8_t *s_sc = fw_smem + ld * lh;                   /* scores, same layout */
@@ -378,6 +379,63 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(OrbGeom g, const uint8_t
        X[k] of fast_is_corner_ld this is two logic ops for both polarities at once.  About a quarter of the pixels
        of a textured image survive; they are queued in row-major order. */
     int nq0 = 0;
+    if (!fast_a0_bytes) {
+        /* FOUR pixels per lane: the aligned dword under the pixels, its neighbours left and right and the dwords three
+           rows up and down -- 5 LDS dword reads instead of 20 byte reads per 4 pixels, one index computation per 4 pixels
+           -- and the test on packed 16-bit halves (even / odd bytes of every dword):
+               brighter on two adjacent compass points  <=>  min(max(N, S), max(E, W)) > v + t
+               darker   on two adjacent compass points  <=>  max(min(N, S), min(E, W)) < v - t
+           six v_pk_min/max_u16 and four v_pk_add/sub per pixel pair.  Same predicate, same queue order (groups walk the
+           zone row-major, a lane appends its pixels left to right behind the pixels of the lanes below it). */
+        const int xb = (3 + ox) & ~3, xe = 3 + ox + iw; /* first aligned x that covers the zone; zone end */
+        const int ng = (iw > 0 && ih > 0) ? (xe - xb + 3) >> 2 : 0;
+        const int ngroups = ng * (ih > 0 ? ih : 0);
+        const float inv_ng = 1.0f / (float)(ng > 0 ? ng : 1);
+        const v2u T = __builtin_bit_cast(v2u, tt);
+        for (int g0 = 0; g0 < ngroups; g0 += 64) {
+            const int g = g0 + lane;
+            uint32_t hits = 0;
+            int x0 = 0, y = 0;
+            if (g < ngroups) {
+                const int yy = (int)(((float)g + 0.5f) * inv_ng);
+                x0 = xb + 4 * (g - __mul24(yy, ng));
+                y = yy + 3;
+                const uint8_t *row = s_px + __mul24(y, ld) + x0;
+                const uint32_t C = *(const uint32_t *)row, L = *(const uint32_t *)(row - 4), R = *(const uint32_t *)(row + 4);
+                const uint32_t N = *(const uint32_t *)(row - 3 * ld), S = *(const uint32_t *)(row + 3 * ld);
+                const uint32_t W = __builtin_amdgcn_alignbyte(C, L, 1), E = __builtin_amdgcn_alignbyte(R, C, 3);
+                uint32_t bits[2];
+#pragma unroll
+                for (int par = 0; par < 2; par++) {
+                    const int sh = par * 8;
+                    const v2u c = __builtin_bit_cast(v2u, (C >> sh) & 0x00FF00FFu), n = __builtin_bit_cast(v2u, (N >> sh) & 0x00FF00FFu),
+                              so = __builtin_bit_cast(v2u, (S >> sh) & 0x00FF00FFu), e = __builtin_bit_cast(v2u, (E >> sh) & 0x00FF00FFu),
+                              we = __builtin_bit_cast(v2u, (W >> sh) & 0x00FF00FFu);
+                    const v2u hi = __builtin_elementwise_min(__builtin_elementwise_max(n, so), __builtin_elementwise_max(e, we));
+                    const v2u lo = __builtin_elementwise_max(__builtin_elementwise_min(n, so), __builtin_elementwise_min(e, we));
+                    const v2s br = __builtin_bit_cast(v2s, (v2u)(c + T)) - __builtin_bit_cast(v2s, hi);  /* < 0: brighter pair */
+                    const v2s dk = __builtin_bit_cast(v2s, lo) - (__builtin_bit_cast(v2s, c) - __builtin_bit_cast(v2s, T)); /* < 0: darker pair */
+                    bits[par] = (__builtin_bit_cast(uint32_t, br) | __builtin_bit_cast(uint32_t, dk)) & 0x80008000u;
+                }
+                /* pixel k of the dword: even halves carry k = 0 (bit 15) and k = 2 (bit 31), odd halves k = 1 and k = 3 */
+                hits = ((bits[0] >> 15) & 1u) | ((bits[1] >> 14) & 2u) | ((bits[0] >> 29) & 4u) | ((bits[1] >> 28) & 8u);
+                /* pixels of the dword outside the detection zone [3 + ox, xe) */
+                const int lo_cut = 3 + ox - x0, hi_cut = xe - x0; /* valid k: lo_cut <= k < hi_cut */
+                uint32_t valid = 0xFu;
+                if (lo_cut > 0) valid &= 0xFu << lo_cut;
+                if (hi_cut < 4) valid &= (1u << hi_cut) - 1u;
+                hits &= valid;
+            }
+            const uint64_t m0 = __ballot(hits & 1u), m1 = __ballot(hits & 2u), m2 = __ballot(hits & 4u), m3 = __ballot(hits & 8u);
+            int pos = nq0 + __popcll(m0 & lt) + __popcll(m1 & lt) + __popcll(m2 & lt) + __popcll(m3 & lt);
+            const int e0 = y << 7 | x0;
+            if (hits & 1u) s_q[pos++] = (uint16_t)e0;
+            if (hits & 2u) s_q[pos++] = (uint16_t)(e0 + 1);
+            if (hits & 4u) s_q[pos++] = (uint16_t)(e0 + 2);
+            if (hits & 8u) s_q[pos++] = (uint16_t)(e0 + 3);
+            nq0 += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+        }
+    } else
     for (int ch = 0; ch < nch; ch++) {
         const int i = ch * 64 + lane;
         bool hit = false;
@@ -477,8 +535,9 @@ hipError_t launch_fast(const OrbGeom &g, const OrbBuffers &b, int n_frames, hipS
     if (g.cell_max_rw > 0) { /* one wavefront per cell */
         const int ld = (g.cell_max_rw + 3 + 3) & ~3, lh = g.cell_max_rh;
         static const int stop_after = getenv("ORBSLAM_AMD_FAST_STOP") ? atoi(getenv("ORBSLAM_AMD_FAST_STOP")) : 0;
+        static const int a0_bytes = getenv("ORBSLAM_AMD_FAST_A0_BYTES") ? 1 : 0; /* diagnostics: the one-pixel-per-lane pre-test */
         hipLaunchKernelGGL(k_fast_cells_wave, grid, dim3(64), (size_t)2 * ld * lh + 2 * (size_t)(g.cell_max_rw * g.cell_max_rh), st, g, (const uint8_t *)b.pyr, b.cells, b.slab,
-                           b.cell_cnt, ld, lh, stop_after);
+                           b.cell_cnt, ld, lh, stop_after, a0_bytes);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, st, g, (const uint8_t *)b.pyr, b.cells, b.slab, b.cell_cnt);
