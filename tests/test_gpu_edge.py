@@ -211,3 +211,63 @@ def test_extractors_on_concurrent_host_threads(oracle):
     for t in threads:
         t.join(300)
     assert not errors, errors
+
+
+def test_tracking_thread_beside_local_mapping_thread(oracle):
+    """the deployment the reference is written for: a Tracking thread (extraction -- HIP-graph capture and replay --,
+    matching, pose optimisation) and a LocalMapping thread (local bundle adjustment, buffers growing from window to
+    window) on their own handles at the same time: every result equals the one computed alone"""
+    import threading
+    import orbslam_in_practice_amd as oa
+    from orbslam_in_practice_amd import synth
+    frames = [synth.make_frame(4100 + k, 640, 480) for k in range(6)]
+    o = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
+    ref_frames = [o.extract(f) for f in frames]
+    wins = [synth.make_ba_window(4200 + k, 10 + 6 * k, 300 + 350 * k) for k in range(4)]
+    for w in wins:
+        w["fixed"][:2] = 1
+    ref_ba = [oracle.ba_solve(w, rounds=(5, 10)) for w in wins]
+    pw = synth.make_ba_window(4300, 6, 400)
+    sel = np.nonzero(pw["cam_idx"] == 2)[0]
+    pxw, pobs, pinfo = pw["gt_points"][pw["pt_idx"][sel]], pw["obs"][sel], pw["inv_sigma2"][sel]
+    ref_pose = oracle.pose_optimization(pw["poses"][2], pxw, pobs, pinfo, pw["fx"], pw["fy"], pw["cx"], pw["cy"])
+    errors = []
+
+    def tracking():
+        try:
+            e = oa.ORBextractor(1000, 1.2, 8, 20, 7, max_w=640, max_h=480, max_batch=1)
+            po = oa.Optimizer(max_cams=8, max_points=1024, max_obs=4096, max_batch=1)
+            for rep in range(8):
+                for k, f in enumerate(frames):
+                    kp, d = e(f)
+                    if not (np.array_equal(kp, ref_frames[k][0]) and np.array_equal(d, ref_frames[k][1])):
+                        errors.append(("extract", rep, k))
+                    p, outl, ninl = po.PoseOptimization(pw["poses"][2], pxw, pobs, pinfo, pw["fx"], pw["fy"], pw["cx"], pw["cy"])
+                    if ninl != ref_pose[2] or not np.array_equal(outl, ref_pose[1]) or np.abs(p - ref_pose[0]).max() > 1e-5:
+                        errors.append(("pose", rep, k))
+            po.close()
+            e.close()
+        except Exception as ex:  # noqa: BLE001
+            errors.append(("tracking", repr(ex)))
+
+    def mapping():
+        try:
+            ba = oa.Optimizer(max_cams=8, max_points=256, max_obs=1024, max_batch=1)   # small on purpose: every window grows it
+            for rep in range(3):
+                for k, w in enumerate(wins):
+                    g = ba.LocalBundleAdjustment(w)
+                    r = ref_ba[k]
+                    if not (np.array_equal(g["outlier"], r["outlier"]) and
+                            np.abs(g["points"] - r["points"]).max() <= 1e-5 * np.abs(r["points"]).max() and
+                            np.abs(g["poses"] - r["poses"]).max() <= 1e-5 * max(np.abs(r["poses"]).max(), 1.0)):
+                        errors.append(("ba", rep, k))
+            ba.close()
+        except Exception as ex:  # noqa: BLE001
+            errors.append(("mapping", repr(ex)))
+
+    ts = [threading.Thread(target=tracking), threading.Thread(target=mapping)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+    assert not errors, errors
