@@ -79,6 +79,7 @@ struct BAWin {
     /* doubles */
     int64_t poses, poses_t, pts, pts_t, obs, info, err, err_t, W, tv, Hpp, bp, Hll, bl, Dinv, S, g, Minv, x, xl, st;
     int64_t A, Linv; /* dense reduced system (np x np) and inverse diagonal blocks of its Cholesky factor */
+    int64_t Uf, tu;  /* per point: the upper-triangular U with Dinv = U U^T (6 doubles) and u = U^T bl (phase-kernel Schur pass) */
     int64_t Rc;      /* rotation matrices of the cameras (9 doubles each), written by the camera pass of the phase-kernel path */
     int64_t S2, g2;  /* second accumulator of the Schur products and of g (phase-kernel path: the window's chunks are split
                         over two workgroups; the Cholesky assembly adds S and S2, g and g2); chunked windows only */
@@ -1386,6 +1387,42 @@ __device__ __forceinline__ double ba_phase_backsub(const BAWin &w, double *D, co
     }
     return scale_loc;
 }
+/* Dinv = (Hll + lambda I)^-1 factored as U U^T (U upper triangular: the inverse transpose of the Cholesky factor of
+   Hll + lambda I) and u = U^T bl.  With Z_e = W_e U the Schur products become S -= sum Z_a Z_b^T and g -= sum Z_e u:
+   W Dinv is formed once per EDGE (36 FMAs at staging) instead of once per contribution (54 in every block product),
+   and a contribution reads 36 doubles from LDS instead of 45.  A point whose matrix is not positive definite in
+   floating point gets NaNs, which fail the Cholesky of S and send the LM trial to a larger lambda -- what an
+   indefinite Dinv does on the other path. */
+__device__ __forceinline__ void ba_phase_ufactor(const BAWin &w, double *D, double lambda, int gtid, int gthreads) {
+    for (int p = gtid; p < w.Np; p += gthreads) {
+        const double *H = D + w.Hll + (int64_t)p * 9;
+        const double a00 = H[0] + lambda, a10 = H[3], a20 = H[6], a11 = H[4] + lambda, a21 = H[7], a22 = H[8] + lambda;
+        const double nan_ = __builtin_nan("");
+        double U[6] = {nan_, nan_, nan_, nan_, nan_, nan_};
+        const double c00 = sqrt(a00), c10 = a10 / c00, c20 = a20 / c00;
+        const double d11 = a11 - c10 * c10;
+        const double c11 = sqrt(d11), c21 = (a21 - c20 * c10) / c11;
+        const double d22 = a22 - c20 * c20 - c21 * c21;
+        const double c22 = sqrt(d22);
+        if (a00 > 0.0 && d11 > 0.0 && d22 > 0.0 && isfinite(c22)) {
+            const double i00 = 1.0 / c00, i11 = 1.0 / c11, i22 = 1.0 / c22;
+            const double i10 = -c10 * i00 * i11, i21 = -c21 * i11 * i22, i20 = -(c20 * i00 + c21 * i10) * i22;
+            U[0] = i00;
+            U[1] = i10;
+            U[2] = i20;
+            U[3] = i11;
+            U[4] = i21;
+            U[5] = i22;
+        }
+        double *Ud = D + w.Uf + (int64_t)p * 6;
+#pragma unroll
+        for (int i = 0; i < 6; i++) Ud[i] = U[i];
+        const double b0 = D[w.bl + (int64_t)p * 3], b1 = D[w.bl + (int64_t)p * 3 + 1], b2 = D[w.bl + (int64_t)p * 3 + 2];
+        D[w.tu + (int64_t)p * 3] = U[0] * b0;
+        D[w.tu + (int64_t)p * 3 + 1] = U[1] * b0 + U[3] * b1;
+        D[w.tu + (int64_t)p * 3 + 2] = U[2] * b0 + U[4] * b1 + U[5] * b2;
+    }
+}
 /* the second accumulator of g starts at zero (S2 needs no fill: part 1 starts the blocks it touches, the assembly
    reads no others) */
 __device__ __forceinline__ void ba_phase_zero2(const BAWin &w, double *D, int gtid, int gthreads) {
@@ -1802,6 +1839,7 @@ template <class SH> __device__ __forceinline__ void ba_ph_dinv(const BAWin &w, d
         if (build) st[ST_QMAX] = 0.0;
     }
     ba_phase_dinv<true>(w, D, I, lambda, threadIdx.x, BA_T);
+    ba_phase_ufactor(w, D, lambda, threadIdx.x, BA_T);
 }
 __device__ __forceinline__ void ba_ph_chol(const BAWin &w, double *D, const int32_t *I, double *dyn, double *bad_flag) {
     double *st = D + w.st;
@@ -1988,6 +2026,7 @@ __global__ __launch_bounds__(BA_PH_T) void k_ba_ph_dinv(BABufs bufs) {
     BA_PH_WINDOW
     if (ph == 2.0) return;
     ba_phase_dinv<true>(w, D, I, D[w.st + ST_LAMBDA], blockIdx.y * BA_PH_T + threadIdx.x, gridDim.y * BA_PH_T);
+    ba_phase_ufactor(w, D, D[w.st + ST_LAMBDA], blockIdx.y * BA_PH_T + threadIdx.x, gridDim.y * BA_PH_T);
     ba_phase_zero2(w, D, blockIdx.y * BA_PH_T + threadIdx.x, gridDim.y * BA_PH_T);
 }
 /* The Schur pass of the phase-kernel path: the window's point chunks are split over two groups of 256 threads,
@@ -2024,11 +2063,11 @@ __device__ __forceinline__ void ba_schur_part(const BAWin &w, double *D, const i
         const int e0 = cd[0], ne = live ? cd[1] - cd[0] : 0, p0 = cd[2], npnt = live ? cd[3] - cd[2] : 0, cb0 = cd[4], ncb = live ? cd[5] - cd[4] : 0;
         const int cg0 = cd[6], ncg = live ? cd[7] - cd[6] : 0, c0 = cd[8], nc = live ? cd[9] : 0, g0 = cd[10], ng = live ? cd[11] : 0;
         { /* every load of the chunk issued before the first LDS write */
-            constexpr int DPT = (BA_CHUNK_P * 9 + BA_SH_T - 1) / BA_SH_T, TPT = (BA_CHUNK_P * 3 + BA_SH_T - 1) / BA_SH_T,
+            constexpr int TPT = (BA_CHUNK_P * 3 + BA_SH_T - 1) / BA_SH_T,
                           EPT = (BA_CHUNK_E + BA_SH_T - 1) / BA_SH_T, CPT = (BA_CHUNK_C + BA_SH_T - 1) / BA_SH_T,
                           BPT = (BA_CHUNK_B + 1 + BA_SH_T - 1) / BA_SH_T;
             double2 rR[EPT][2];
-            double rD[DPT], rT[TPT];
+            double rT[TPT];
             int32_t rCam[EPT], rP[EPT], rG[EPT], rC[CPT], rB[BPT], rBS[BPT];
 #pragma unroll
             for (int k = 0; k < EPT; k++) {
@@ -2041,9 +2080,7 @@ __device__ __forceinline__ void ba_schur_part(const BAWin &w, double *D, const i
                 rG[k] = el < ng ? I[w.cg_edge + g0 + el] : 0;
             }
 #pragma unroll
-            for (int k = 0; k < DPT; k++) rD[k] = tid + k * BA_SH_T < npnt * 9 ? D[w.Dinv + (int64_t)p0 * 9 + tid + k * BA_SH_T] : 0.0;
-#pragma unroll
-            for (int k = 0; k < TPT; k++) rT[k] = tid + k * BA_SH_T < npnt * 3 ? D[w.tv + (int64_t)p0 * 3 + tid + k * BA_SH_T] : 0.0;
+            for (int k = 0; k < TPT; k++) rT[k] = tid + k * BA_SH_T < npnt * 3 ? D[w.tu + (int64_t)p0 * 3 + tid + k * BA_SH_T] : 0.0;
 #pragma unroll
             for (int k = 0; k < CPT; k++) rC[k] = tid + k * BA_SH_T < nc ? I[w.cb_con + c0 + tid + k * BA_SH_T] : 0;
 #pragma unroll
@@ -2051,11 +2088,14 @@ __device__ __forceinline__ void ba_schur_part(const BAWin &w, double *D, const i
                 rB[k] = tid + k * BA_SH_T < ncb ? I[w.cb_blk + cb0 + tid + k * BA_SH_T] : 0;
                 rBS[k] = tid + k * BA_SH_T <= ncb ? I[w.cb_start + cb0 + tid + k * BA_SH_T] - c0 : 0;
             }
-            double rRot[EPT][9];
+            double rRot[EPT][9], rU[EPT][6];
 #pragma unroll
-            for (int k = 0; k < EPT; k++)
+            for (int k = 0; k < EPT; k++) {
 #pragma unroll
                 for (int i = 0; i < 9; i++) rRot[k][i] = D[w.Rc + (int64_t)rCam[k] * 9 + i];
+#pragma unroll
+                for (int i = 0; i < 6; i++) rU[k][i] = D[w.Uf + (int64_t)(p0 + rP[k]) * 6 + i];
+            }
 #pragma unroll
             for (int k = 0; k < EPT; k++) { /* the W tile: one edge per thread, rebuilt from its record */
                 const int el = tid + k * BA_SH_T;
@@ -2063,15 +2103,20 @@ __device__ __forceinline__ void ba_schur_part(const BAWin &w, double *D, const i
                     const double rec[4] = {rR[k][0].x, rR[k][0].y, rR[k][1].x, el < ne ? rR[k][1].y : 0.0};
                     double Wr[18];
                     ba_w_from_record(rec, rRot[k], w.fx, w.fy, Wr);
+                    double Z[18]; /* Z = W U */
 #pragma unroll
-                    for (int i = 0; i < 9; i++) ((double2 *)(sW + el * 18))[i] = double2{Wr[2 * i], Wr[2 * i + 1]};
+                    for (int r = 0; r < 6; r++) {
+                        const double w0 = Wr[r * 3], w1 = Wr[r * 3 + 1], w2 = Wr[r * 3 + 2];
+                        Z[r * 3] = w0 * rU[k][0];
+                        Z[r * 3 + 1] = w0 * rU[k][1] + w1 * rU[k][3];
+                        Z[r * 3 + 2] = w0 * rU[k][2] + w1 * rU[k][4] + w2 * rU[k][5];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 9; i++) ((double2 *)(sW + el * 18))[i] = double2{Z[2 * i], Z[2 * i + 1]};
                     sP[el] = rP[k];
                     sG[el] = rG[k];
                 }
             }
-#pragma unroll
-            for (int k = 0; k < DPT; k++)
-                if (tid + k * BA_SH_T < BA_CHUNK_P * 9) sD[tid + k * BA_SH_T] = rD[k];
 #pragma unroll
             for (int k = 0; k < TPT; k++)
                 if (tid + k * BA_SH_T < BA_CHUNK_P * 3) sT[tid + k * BA_SH_T] = rT[k];
@@ -2120,17 +2165,12 @@ __device__ __forceinline__ void ba_schur_part(const BAWin &w, double *D, const i
             for (int i = 0; i < 36; i++) acc[i] = 0.0;
             for (int k = (skip & 256) ? k1 : k0 + l16; k < k1; k += 16) {
                 const uint32_t ab = (uint32_t)sC[k];
-                const double *Wa = sW + (ab & 511) * 18, *Wb = sW + ((ab >> 9) & 511) * 18, *Iv = sD + (ab >> 18) * 9;
+                const double *Za = sW + (ab & 511) * 18, *Zb = sW + ((ab >> 9) & 511) * 18;
                 double y[18], ww[18];
 #pragma unroll
-                for (int r = 0; r < 6; r++) {
-                    const double w0 = Wa[r * 3], w1 = Wa[r * 3 + 1], w2 = Wa[r * 3 + 2];
-                    y[r * 3] = w0 * Iv[0] + w1 * Iv[3] + w2 * Iv[6];
-                    y[r * 3 + 1] = w0 * Iv[1] + w1 * Iv[4] + w2 * Iv[7];
-                    y[r * 3 + 2] = w0 * Iv[2] + w1 * Iv[5] + w2 * Iv[8];
-                }
+                for (int i = 0; i < 18; i++) y[i] = Za[i];
 #pragma unroll
-                for (int i = 0; i < 18; i++) ww[i] = Wb[i];
+                for (int i = 0; i < 18; i++) ww[i] = Zb[i];
 #pragma unroll
                 for (int r = 0; r < 6; r++)
 #pragma unroll
@@ -2359,7 +2399,7 @@ static int64_t BAWin::*const kScratchFields[] = {&BAWin::poses_t, &BAWin::pts_t,
                                                  &BAWin::tv,      &BAWin::Hpp,   &BAWin::bp,  &BAWin::Hll,   &BAWin::bl,
                                                  &BAWin::Dinv,    &BAWin::S,     &BAWin::g,   &BAWin::Minv,  &BAWin::x,
                                                  &BAWin::xl,      &BAWin::A,     &BAWin::Linv, &BAWin::gred,  &BAWin::pcgv,
-                                                 &BAWin::S2,      &BAWin::g2,    &BAWin::Rc};
+                                                 &BAWin::S2,      &BAWin::g2,    &BAWin::Rc,   &BAWin::Uf,    &BAWin::tu};
 #define BA_CHOL_LDS_BYTES (128 * 1024) /* dynamic LDS the blocked Cholesky may take beside the static 25 KB */
 
 /* Lay one problem out in the host staging vectors; returns an error code.  `team`: the window will be spread over
@@ -2628,6 +2668,8 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hO, std::vecto
     w.S = allocS((size_t)nnzb * 36);
     w.g = allocS((size_t)Ncf * 6);
     w.Rc = allocS((size_t)Nc * 9);
+    w.Uf = chunked ? allocS((size_t)Np * 6) : 0;
+    w.tu = chunked ? allocS((size_t)Np * 3) : 0;
     w.S2 = chunked ? allocS((size_t)nnzb * 36) : w.S; /* (never read when the window is not chunked) */
     w.g2 = chunked ? allocS((size_t)Ncf * 6) : w.g;
     w.Minv = allocS((size_t)Ncf * 36);
