@@ -52,7 +52,7 @@ template <class FrameT> class ORBmatcherT {
   public:
     ORBmatcherT(float nnratio = 0.6, bool checkOri = true)
         : mfNNratio(nnratio), mbCheckOrientation(checkOri), m_(nullptr), cap_(0) {}
-    ~ORBmatcherT() { orb_matcher_destroy(m_); }
+    ~ORBmatcherT() {} /* (the device handle belongs to the host thread, see ensure()) */
     ORBmatcherT(const ORBmatcherT &) = delete;
     ORBmatcherT &operator=(const ORBmatcherT &) = delete;
 
@@ -227,12 +227,29 @@ template <class FrameT> class ORBmatcherT {
             b[3] = 480.f;
         }
     }
+    /* The reference constructs an ORBmatcher wherever it needs one (src/Tracking.cpp:293, 333: once per frame), which
+       costs it nothing; a device handle (streams, device and pinned buffers) per object would cost milliseconds per
+       frame.  The handle therefore belongs to the HOST THREAD -- one per thread, grown on demand, released when the
+       thread ends -- and every ORBmatcher object of that thread borrows it (nnratio / checkOri travel with each call). */
+    struct ThreadHandle {
+        OrbMatcher *m = nullptr;
+        int cap = 0;
+        ~ThreadHandle() { orb_matcher_destroy(m); }
+    };
+    static ThreadHandle &thread_handle() {
+        static thread_local ThreadHandle h;
+        return h;
+    }
     void ensure(int n) {
-        if (m_ && n <= cap_) return;
-        orb_matcher_destroy(m_);
-        m_ = nullptr;
-        cap_ = n < 4096 ? 4096 : n;
-        if (orb_matcher_create(cap_, 1, 0, &m_) != ORB_OK) orbslam_amd_fatal("ORBmatcher");
+        ThreadHandle &h = thread_handle();
+        if (!(h.m && n <= h.cap)) {
+            orb_matcher_destroy(h.m);
+            h.m = nullptr;
+            h.cap = n < 4096 ? 4096 : n;
+            if (orb_matcher_create(h.cap, 1, 0, &h.m) != ORB_OK) orbslam_amd_fatal("ORBmatcher");
+        }
+        m_ = h.m;
+        cap_ = h.cap;
     }
     static const int HISTO_LENGTH = 30;
     static const int TH_LOW = 50;
