@@ -111,6 +111,9 @@ int main(int argc, char **argv) {
     int ba_runs = 0;
     bool mbAbortBA = false;
     double t_ba = 0.0, t_first = 0.0; /* seconds inside LocalBundleAdjustment; frame 0 (one-time set-up of the handles) */
+    double t_ext = 0.0, t_sbp = 0.0, t_po = 0.0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
 
     auto new_points_and_keyframe = [&](Frame &F, int frame_id) {
         const Eigen::Matrix3d R = F.GetR();
@@ -155,7 +158,9 @@ int main(int argc, char **argv) {
     double tv[3] = {0, 0, 0};
     for (int k = 1; k < n; k++) {
         cv::Mat im(h, w, CV_8UC1, raw.data() + (size_t)k * w * h);
+        auto tq = now();
         Frame mCurframe(im, mpOrbextractor);
+        t_ext += since(tq);
         /* constant-velocity prediction (Tracking::TrackWithMotionModel) */
         const Eigen::Matrix3d Rl = mLastFrame.GetR();
         const Eigen::Vector3d tl = mLastFrame.GetT();
@@ -167,6 +172,7 @@ int main(int argc, char **argv) {
                 tp[i] = Rv(i, 0) * tl(0) + Rv(i, 1) * tl(1) + Rv(i, 2) * tl(2) + tv[i];
             }
         mCurframe.SetPose(make_T(Rp, tp));
+        tq = now();
         ORBmatcher matcher(0.9, true); /* src/Tracking.cpp:333 */
         int nmatches = matcher.SearchByProjection(mCurframe, mLastFrame, th, true);
         if (nmatches < 20) { /* src/Tracking.cpp:347-351 */
@@ -174,7 +180,10 @@ int main(int argc, char **argv) {
             nmatches = matcher.SearchByProjection(mCurframe, mLastFrame, 2 * th, true);
         }
         out_nm[k] = nmatches;
+        t_sbp += since(tq);
+        tq = now();
         out_inl[k] = Optimizer::PoseOptimization(&mCurframe); /* src/Tracking.cpp:355 */
+        t_po += since(tq);
         for (size_t i = 0; i < mCurframe.mvpMappts.size(); i++) /* :357-370: the outlier associations are dropped */
             if (mCurframe.mvpMappts[i] && mCurframe.mvbOutlier[i]) {
                 mCurframe.mvpMappts[i] = nullptr;
@@ -230,5 +239,7 @@ int main(int argc, char **argv) {
     std::printf("tracking_main: %d frames in %.3f s = %.1f frames/s (frame 0 with the handles' set-up %.3f s; %d local BAs %.3f s; "
                 "tracking alone %.1f frames/s), %d map points\n",
                 n, secs, n / secs, t_first, ba_runs, t_ba, (n - 1) / (secs - t_first - t_ba), npts);
+    std::printf("  per frame: Frame(im, &extractor) %.3f ms, SearchByProjection %.3f ms, PoseOptimization %.3f ms\n", t_ext / (n - 1) * 1e3,
+                t_sbp / (n - 1) * 1e3, t_po / (n - 1) * 1e3);
     return 0;
 }
