@@ -26,7 +26,9 @@ gt.astype(np.float64).tofile(td + "/gt.bin")
 for rep in range(2):  # (the second run has warm file caches and device clocks)
     out = subprocess.run([exe, "640", "480", str(n), td + "/f.raw", td + "/gt.bin", *("%.17g" % v for v in K), td + "/out.bin"],
                          capture_output=True, text=True)
-    print(out.stdout.strip(), out.stderr.strip()[-300:])
+    print(out.stdout.strip())
+    if out.stderr.strip():
+        print(out.stderr.strip()[-int(os.environ.get("STDERR_TAIL", "300")):])
 raw = open(td + "/out.bin", "rb").read()
 rec = np.frombuffer(raw, np.dtype([("pose", "<f8", 7), ("nm", "<i4"), ("inl", "<i4")]), n, 4)
 print("ATE %.4f m, mean matches %.0f" % (sq.ate_rmse(rec["pose"].copy(), gt), rec["nm"][1:].mean()))
