@@ -350,6 +350,18 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(OrbGeom g, const uint8_t
     const uint8_t *src = level_ptr(pyr, g, frame, cd.level) + (int64_t)cd.iniY * L.pitch + (cd.iniX & ~3);
     const int ndw = (ox + rw + 3) >> 2; /* aligned dwords per ROI row (the pitch is a multiple of 64) */
     const float inv_ndw = 1.0f / (float)ndw; /* i / ndw without the integer divide: exact for i < 2^12 */
+    if (ndw <= 16 && !fast_a0_bytes) {
+        /* lane -> (row lane / 16, dword column lane % 16): no division per element, the row step is a pointer increment;
+           the lanes of columns >= ndw idle (ROI rows are 9 .. 11 dwords at 640 x 480) */
+        const int c4 = lane & 15;
+        if (c4 < ndw) {
+            const uint8_t *g = src + __mul24(lane >> 4, L.pitch) + c4 * 4;
+            uint8_t *d = s_px + __mul24(lane >> 4, ld) + c4 * 4;
+            const int gstep = 4 * L.pitch, dstep = 4 * ld;
+#pragma unroll 4
+            for (int r = lane >> 4; r < rh; r += 4, g += gstep, d += dstep) *(uint32_t *)d = *(const uint32_t *)g;
+        }
+    } else
     for (int i = lane; i < rh * ndw; i += 64) {
         const int r = (int)(((float)i + 0.5f) * inv_ndw), c4 = i - __mul24(r, ndw);
         *(uint32_t *)(s_px + __mul24(r, ld) + c4 * 4) = *(const uint32_t *)(src + __mul24(r, L.pitch) + c4 * 4);
