@@ -83,6 +83,8 @@ def test_cpp_dropin_headers_compile(tmp_path):
     from tests.test_gpu_dropin import build_dropin
     exe = build_dropin(str(tmp_path), extra=["-Wall", "-Wextra", "-Werror"])
     assert os.path.exists(exe)
+    # ... and the Tracking + LocalMapping style loop written on them (tests/cpp/tracking_main.cpp)
+    assert os.path.exists(build_dropin(str(tmp_path), extra=["-O1", "-Wall", "-Wextra", "-Werror"], program="tracking_main"))
 
 
 def test_dropin_headers_standalone():

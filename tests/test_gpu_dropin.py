@@ -13,14 +13,14 @@ G = os.path.join(ROOT, "tests", "golden")
 REL = 1e-5
 
 
-def build_dropin(outdir, extra=()):
-    """compile + link tests/cpp/dropin_main.cpp; include path as in the reference tree: the drop-in headers by their
+def build_dropin(outdir, extra=(), program="dropin_main"):
+    """compile + link tests/cpp/<program>.cpp; include path as in the reference tree: the drop-in headers by their
     reference names ("ORBmatcher.h", "Optimizer.h") and a "Frame.h" / "KeyFrame.h" next to them"""
     lib = os.path.join(ROOT, "orbslam_in_practice_amd", "csrc")
-    exe = os.path.join(outdir, "dropin_main")
+    exe = os.path.join(outdir, program)
     subprocess.check_call(["g++", "-std=c++17", "-O1", *extra, "-I", os.path.join(ROOT, "include"),
                            "-I", os.path.join(ROOT, "include", "orbslam_amd"), "-I", os.path.join(ROOT, "tests", "cpp", "refmodel"),
-                           os.path.join(ROOT, "tests", "cpp", "dropin_main.cpp"), "-o", exe, "-L", lib, "-lorbslam_amd",
+                           os.path.join(ROOT, "tests", "cpp", program + ".cpp"), "-o", exe, "-L", lib, "-lorbslam_amd",
                            "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-lpthread"])
     return exe
 

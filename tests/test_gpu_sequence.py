@@ -40,13 +40,8 @@ def test_tracking_loop_in_cpp_on_the_dropin_classes(tmp_path):
     import os
     import subprocess
     from orbslam_in_practice_amd import sequence as sq
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    lib = os.path.join(root, "orbslam_in_practice_amd", "csrc")
-    exe = str(tmp_path / "tracking_main")
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
-                           "-I", os.path.join(root, "include", "orbslam_amd"), "-I", os.path.join(root, "tests", "cpp", "refmodel"),
-                           os.path.join(root, "tests", "cpp", "tracking_main.cpp"), "-o", exe, "-L", lib, "-lorbslam_amd",
-                           "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-lpthread"])
+    from tests.test_gpu_dropin import build_dropin
+    exe = build_dropin(str(tmp_path), extra=["-O2", "-Wall", "-Wextra", "-Werror"], program="tracking_main")
     n = 33
     frames, gt, K, _ = sq.make_plane_sequence(5, n)
     frames.tofile(str(tmp_path / "frames.raw"))
