@@ -1794,7 +1794,8 @@ struct BARed {
     double bc[8];
 };
 #define BA_PH_SPARE 2
-#define BA_SPLIT_MIN_WINDOWS 129 /* below that the windows get teams (ba_choose_team) */
+#define BA_SPLIT_MIN_WINDOWS 129 /* batches of small windows: phase kernels from here on */
+#define BA_SPLIT_MIN_BIG 6       /* batches of windows big enough for a team (>= 1400 edges): phase kernels from here on */
 
 __global__ void k_ba_ph_round(BABufs bufs, int nwin, int n_iters) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3002,6 +3003,20 @@ static int ba_stage(BASolver *s, BAJob &J, const BAProblem *probs, BAResult *res
     int maxE = 0;
     for (int i = 0; i < nwin; i++) maxE = std::max(maxE, probs[i].n_obs);
     J.team = ba_choose_team(s, nwin, maxE);
+    /* Phase kernels instead of teams from a handful of windows on (decided here because it decides the staging: point
+       chunks for the phase kernels, per-block lists for teams).  Measured at 100 x 5000 (ms of kernel time per batch,
+       teams / phase kernels): 4 windows 12.8 / 16.7, 8: 19.6 / 16.9, 16: 40.4 / 18.5, 32: 41.9 / 22.3, 64: 55.8 / 25.1,
+       128: 81.6 / 29.1 -- a team's barriers and per-block Schur lists do not scale to many teams at once, while the
+       phase kernels spread every window's streaming phases over the machine by themselves.  Small windows (a team of
+       one anyway) stay on the fused kernel until the batch is large: their trials are shorter than the launches. */
+    {
+        bool any_stop = false;
+        for (int i = 0; i < nwin; i++) any_stop |= probs[i].stop != nullptr;
+        const bool wanted = s->force_split == 1 || nwin >= BA_SPLIT_MIN_WINDOWS || (nwin >= BA_SPLIT_MIN_BIG && maxE / 700 >= 2);
+        if (wanted && s->force_split != 0 && s->force_team == 0 && s->solver == 1 && !any_stop && !getenv("ORBSLAM_AMD_BA_PROFILE") &&
+            !getenv("ORBSLAM_AMD_BA_DEBUG"))
+            J.team = 1;
+    }
     const bool team = J.team > 1;
     if ((int)s->pieces.size() < nwin) s->pieces.resize(nwin);
     std::vector<BAPiece> &pieces = s->pieces;
@@ -3137,7 +3152,11 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
         chol_doubles = std::max(chol_doubles, need);
     }
     if (s->force_split == 0) split = false;
-    if (s->force_split != 1 && nwin < BA_SPLIT_MIN_WINDOWS) split = false;
+    {
+        int maxE_ = 0;
+        for (int i = 0; i < nwin; i++) maxE_ = std::max(maxE_, J.wins[i].E);
+        if (s->force_split != 1 && nwin < BA_SPLIT_MIN_WINDOWS && !(nwin >= BA_SPLIT_MIN_BIG && maxE_ / 700 >= 2)) split = false;
+    }
     J.split = split;
     if (split) {
         static PerDeviceLdsLimit lim_schur, lim_chol, lim_fin;
