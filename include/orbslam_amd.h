@@ -249,7 +249,7 @@ int ba_wait(BASolver *s);
 /* measurement hooks: with profiling enabled the device work of every optimize() round is bracketed by HIP events on
  * the solver's stream; after a batch has finished, ba_get_iteration_ms returns the average duration of these
  * intervals, their number, and the workgroups per window (team size) the fused iteration kernel ran with -- 0 when
- * the batch ran as phase kernels (six or more full-size windows or more than 128 of any size, all on the dense Cholesky: an LM trial is then a
+ * the batch ran as phase kernels (six or more windows -- four when none has 16000 observations --, all on the dense Cholesky: an LM trial is then a
  * sequence of kernels over all windows instead of one kernel per window). */
 int ba_set_profiling(BASolver *s, int enable);
 int ba_get_iteration_ms(BASolver *s, float *avg_ms, int32_t *n_launches, int32_t *team);

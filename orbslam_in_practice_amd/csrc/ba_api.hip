@@ -1794,8 +1794,11 @@ struct BARed {
     double bc[8];
 };
 #define BA_PH_SPARE 2
-#define BA_SPLIT_MIN_WINDOWS 129 /* batches of small windows: phase kernels from here on */
-#define BA_SPLIT_MIN_BIG 6       /* batches of windows big enough for a team (>= 1400 edges): phase kernels from here on */
+/* phase kernels from this many windows on: 6, or 4 when no window has BA_SPLIT_BIG_EDGES edges (ba_stage has the
+   measurements) */
+#define BA_SPLIT_MIN_WINDOWS 6
+#define BA_SPLIT_MIN_SMALL 4
+#define BA_SPLIT_BIG_EDGES 16000
 
 __global__ void k_ba_ph_round(BABufs bufs, int nwin, int n_iters) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3003,16 +3006,19 @@ static int ba_stage(BASolver *s, BAJob &J, const BAProblem *probs, BAResult *res
     int maxE = 0;
     for (int i = 0; i < nwin; i++) maxE = std::max(maxE, probs[i].n_obs);
     J.team = ba_choose_team(s, nwin, maxE);
-    /* Phase kernels instead of teams from a handful of windows on (decided here because it decides the staging: point
-       chunks for the phase kernels, per-block lists for teams).  Measured at 100 x 5000 (ms of kernel time per batch,
-       teams / phase kernels): 4 windows 12.8 / 16.7, 8: 19.6 / 16.9, 16: 40.4 / 18.5, 32: 41.9 / 22.3, 64: 55.8 / 25.1,
-       128: 81.6 / 29.1 -- a team's barriers and per-block Schur lists do not scale to many teams at once, while the
-       phase kernels spread every window's streaming phases over the machine by themselves.  Small windows (a team of
-       one anyway) stay on the fused kernel until the batch is large: their trials are shorter than the launches. */
+    /* Phase kernels instead of teams (or one workgroup per window) from a handful of windows on -- decided here because
+       it decides the staging: point chunks for the phase kernels, per-block lists for teams.  Measured, ms of kernel
+       time per batch, teams or fused / phase kernels:
+           100 x 5000 (28 k edges): 1 window 9.0 / 16.0, 3: 11.4 / 16.8, 5: 14.7 / 17.1, 8: 19.6 / 16.9, 16: 40.4 / 18.5,
+                                    32: 41.9 / 22.3, 64: 55.8 / 25.1, 128: 81.6 / 29.1
+           50 x 2000 (11 k edges):  4 windows 8.8 / 8.2, 8: 16.4 / 9.0, 16: 34.0 / 9.7, 64: 36.7 / 10.7
+           20 x 300:                8 windows 4.2 / 3.5, 32: 6.9 / 3.5, 128: 23.0 / 4.0          8 x 150: equal
+       A team's barriers and per-block Schur lists do not scale to many teams at once, while the phase kernels spread
+       every window's streaming phases over the machine by themselves. */
     {
         bool any_stop = false;
         for (int i = 0; i < nwin; i++) any_stop |= probs[i].stop != nullptr;
-        const bool wanted = s->force_split == 1 || nwin >= BA_SPLIT_MIN_WINDOWS || (nwin >= BA_SPLIT_MIN_BIG && maxE / 700 >= 2);
+        const bool wanted = s->force_split == 1 || nwin >= BA_SPLIT_MIN_WINDOWS || (nwin >= BA_SPLIT_MIN_SMALL && maxE < BA_SPLIT_BIG_EDGES);
         if (wanted && s->force_split != 0 && s->force_team == 0 && s->solver == 1 && !any_stop && !getenv("ORBSLAM_AMD_BA_PROFILE") &&
             !getenv("ORBSLAM_AMD_BA_DEBUG"))
             J.team = 1;
@@ -3155,7 +3161,7 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
     {
         int maxE_ = 0;
         for (int i = 0; i < nwin; i++) maxE_ = std::max(maxE_, J.wins[i].E);
-        if (s->force_split != 1 && nwin < BA_SPLIT_MIN_WINDOWS && !(nwin >= BA_SPLIT_MIN_BIG && maxE_ / 700 >= 2)) split = false;
+        if (s->force_split != 1 && nwin < BA_SPLIT_MIN_WINDOWS && !(nwin >= BA_SPLIT_MIN_SMALL && maxE_ < BA_SPLIT_BIG_EDGES)) split = false;
     }
     J.split = split;
     if (split) {

@@ -160,9 +160,11 @@ def test_ba_batch_equals_single(opt, oracle):
     batch = opt.solve_batch(ws, (5, 10))
     for w, b in zip(ws, batch):
         single = opt.solve_batch([w], (5, 10))[0]
-        # no atomics anywhere: bit-reproducible for a given team size; the team size (workgroups per window) follows
-        # the batch's largest window, so a window solved alone may sum in another order -- rounding level only
-        assert _rel(single["points"], b["points"]) < 1e-9
+        # no atomics anywhere: bit-reproducible for a given launch shape; a window solved alone runs on a team of
+        # workgroups, the batch (four windows or more) as phase kernels -- another summation order and W rebuilt from its
+        # edge records: rounding level only, far below the 1e-5 both are held to
+        assert _rel(single["points"], b["points"]) < 1e-7
+        assert np.array_equal(single["outlier"], b["outlier"])
         ref = oracle.ba_solve(w, rounds=(5, 10))
         assert _rel(b["points"], ref["points"]) < REL
 
