@@ -2406,6 +2406,29 @@ static int64_t BAWin::*const kScratchFields[] = {&BAWin::poses_t, &BAWin::pts_t,
                                                  &BAWin::S2,      &BAWin::g2,    &BAWin::Rc,   &BAWin::Uf,    &BAWin::tu};
 #define BA_CHOL_LDS_BYTES (128 * 1024) /* dynamic LDS the blocked Cholesky may take beside the static 25 KB */
 
+/* Point chunks or per-block lists for a window's Schur complement?  The chunked pass streams a window's edges once and
+ * wins while the points of a chunk pile several contributions onto a block.  In a map with LONG tracks every point
+ * touches k (k + 1) / 2 blocks: at 23 observing keyframes a single point no longer fits a chunk (BA_CHUNK_B blocks), and
+ * cutting its pair list over several chunks loses badly (one contribution per (block, chunk) pair: 615 ms against 71 for
+ * 32 windows of 40 keyframes x 1500 points with tracks of 30) -- there the per-block lists win, whose owners walk ~1000
+ * contributions each.  Measured on that shape, kernel ms per 32-window batch, teams + lists / phase kernels + chunks:
+ * tracks of 8: 25.4 / 8.0, 12: 35.4 / 10.4, 15: 40.9 / 15.6, 18: 48.3 / 22.6, 22: 50.1 / 38.5, 26 (with 480 blocks per
+ * chunk): 70.2 / 69.4, 30: 71.2 / 122.5.  So: chunks when no point is seen by more than BA_CHUNK_MAX_TRACK free
+ * keyframes (and the mean does not exceed BA_CHUNK_MEAN_TRACK), lists otherwise. */
+#define BA_CHUNK_MAX_TRACK 22
+#define BA_CHUNK_MEAN_TRACK 22
+static bool ba_window_chunkable(const BAProblem *p) {
+    static const int mean_track = getenv("ORBSLAM_AMD_BA_MEAN_TRACK") ? atoi(getenv("ORBSLAM_AMD_BA_MEAN_TRACK")) : BA_CHUNK_MEAN_TRACK; /* (diagnostics) */
+    if (p->n_points <= 0 || (long)p->n_obs > (long)mean_track * p->n_points) return false;
+    std::vector<int> deg(p->n_points, 0);
+    for (int e = 0; e < p->n_obs; e++) {
+        const int c = p->cam_idx[e], q = p->pt_idx[e];
+        if (c < 0 || c >= p->n_cams || q < 0 || q >= p->n_points) return false; /* (stage_problem reports it) */
+        if (!p->fixed[c] && ++deg[q] > BA_CHUNK_MAX_TRACK) return false;
+    }
+    return true;
+}
+
 /* Lay one problem out in the host staging vectors; returns an error code.  `team`: the window will be spread over
  * several workgroups (or is too irregular for point chunks) -> per-block contribution lists; otherwise point
  * chunks for the LDS-staged Schur pass of the batch path. */
@@ -2507,7 +2530,7 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hO, std::vecto
     for (int s1 = 0; s1 < Ncf; s1++)
         for (int bk = brow[s1]; bk < brow[s1 + 1]; bk++) bmirror[bk] = blk[(size_t)bcol[bk] * Ncf + s1];
     const int ncon = ccount[nnzb];
-    const bool chunked = !team && max_deg <= BA_CHUNK_E && Ncf > 0;
+    const bool chunked = !team && max_deg <= BA_CHUNK_E && Ncf > 0 && ba_window_chunkable(p);
     /* ---- list path: per block, the edge pairs (a, b) of the points both cameras see ---- */
     std::vector<int> ce1, ce2;
     if (!chunked) {
@@ -2537,22 +2560,49 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hO, std::vecto
         std::vector<int> blk_pos(nnzb, 0), slot_pos(Ncf, 0);
         std::vector<int> cb_cnt, cg_cnt, tmp_blk, tmp_slot;
         bool chunk_overflow = false;
+        std::vector<int> grow_blk(nnzb, -1); /* growth attempt that last counted the block */
+        int grow_stamp = 0;
         int p0 = 0;
         while (p0 < Np) {
             int p1 = p0;
+            long first_pairs = 0;
             {
-                /* as many consecutive points as the LDS tiles hold: edges, points, contributions (k (k + 1) / 2 per point
-                   at most), and a bound on the blocks touched (every pair of a point's free cameras at most) */
-                long ncon_c = 0;
+                /* as many consecutive points as the LDS tiles hold: edges, points, contributions (one per pair of a point's
+                   free cameras) and distinct blocks touched.  The first point is taken whatever it needs (below). */
+                long ncon_c = 0, nblk_c = 0;
+                grow_stamp++;
                 while (p1 < Np && p1 - p0 < BA_CHUNK_P && cnt[p1 + 1] - cnt[p0] <= BA_CHUNK_E) {
-                    const long k = cnt[p1 + 1] - cnt[p1];
-                    if (p1 > p0 && (ncon_c + k * (k + 1) / 2 > BA_CHUNK_C)) break;
-                    ncon_c += k * (k + 1) / 2;
+                    long pairs = 0, newb = 0;
+                    for (int a = cnt[p1]; a < cnt[p1 + 1]; a++) {
+                        const int s1 = eslot[a];
+                        if (s1 < 0) continue;
+                        const int *row = &blk[(size_t)s1 * Ncf];
+                        for (int b = cnt[p1]; b < cnt[p1 + 1]; b++) {
+                            const int s2 = eslot[b];
+                            if (s2 < s1) continue;
+                            pairs++;
+                            if (grow_blk[row[s2]] != grow_stamp) newb++; /* (counted again below if the point is taken) */
+                        }
+                    }
+                    if (p1 > p0 && (ncon_c + pairs > BA_CHUNK_C || nblk_c + newb > BA_CHUNK_B)) break;
+                    for (int a = cnt[p1]; a < cnt[p1 + 1]; a++) {
+                        const int s1 = eslot[a];
+                        if (s1 < 0) continue;
+                        const int *row = &blk[(size_t)s1 * Ncf];
+                        for (int b = cnt[p1]; b < cnt[p1 + 1]; b++)
+                            if (eslot[b] >= s1 && grow_blk[row[eslot[b]]] != grow_stamp) {
+                                grow_blk[row[eslot[b]]] = grow_stamp;
+                                nblk_c++;
+                            }
+                    }
+                    ncon_c += pairs;
+                    if (p1 == p0) first_pairs = pairs;
                     p1++;
                 }
             }
-            /* (p1 > p0: a single point never exceeds BA_CHUNK_E edges here; one with more than BA_CHUNK_C contributions
-               or BA_CHUNK_B blocks sends the window to the list path below) */
+            /* (a single point with more pairs than a chunk holds cannot occur: ba_window_chunkable() keeps such windows
+               on the per-block lists; the check below stays as the safety net) */
+            (void)first_pairs;
             const int e0 = cnt[p0], e1 = cnt[p1], chid = (int)chd.size() / BA_CH_DESC;
             /* pass 1: which blocks / cameras does the chunk touch, and how many contributions each */
             tmp_blk.clear();
@@ -3020,8 +3070,17 @@ static int ba_stage(BASolver *s, BAJob &J, const BAProblem *probs, BAResult *res
         for (int i = 0; i < nwin; i++) any_stop |= probs[i].stop != nullptr;
         const bool wanted = s->force_split == 1 || nwin >= BA_SPLIT_MIN_WINDOWS || (nwin >= BA_SPLIT_MIN_SMALL && maxE < BA_SPLIT_BIG_EDGES);
         if (wanted && s->force_split != 0 && s->force_team == 0 && s->solver == 1 && !any_stop && !getenv("ORBSLAM_AMD_BA_PROFILE") &&
-            !getenv("ORBSLAM_AMD_BA_DEBUG"))
-            J.team = 1;
+            !getenv("ORBSLAM_AMD_BA_DEBUG")) {
+            /* ... and only when every window is one for point chunks (long tracks stay with teams and per-block lists) */
+            std::vector<uint8_t> okw(nwin, 0);
+            const int nt = std::max(1, std::min<int>(nwin, std::min<int>(16, (int)std::thread::hardware_concurrency())));
+            ba_parallel(nt, [&](int t) {
+                for (int i = t; i < nwin; i += nt) okw[i] = ba_window_chunkable(&probs[i]) ? 1 : 0;
+            });
+            bool all_ok = true;
+            for (int i = 0; i < nwin; i++) all_ok = all_ok && okw[i];
+            if (all_ok) J.team = 1;
+        }
     }
     const bool team = J.team > 1;
     if ((int)s->pieces.size() < nwin) s->pieces.resize(nwin);

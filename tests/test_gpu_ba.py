@@ -380,42 +380,58 @@ def test_ba_more_than_256_free_cameras(oracle):
     o.close()
 
 
-def test_ba_point_seen_by_every_camera_takes_the_list_path(opt, oracle):
-    """a point observed by all 100 keyframes has 5050 contributions to the reduced system -- more than a point chunk of
-    the LDS-staged Schur pass holds: such a window falls back to the per-block lists (also inside a batch) and still
-    agrees with the oracle"""
+def test_ba_point_seen_by_every_camera(oracle, monkeypatch):
+    """two points per window observed by all 100 keyframes: 4851 contributions each to the reduced system, every one to
+    another block -- nineteen times what a point chunk of the LDS-staged Schur pass holds.  Long tracks are what the
+    per-block lists are for (ba_window_chunkable): such windows keep teams and lists also in a batch, and the fused
+    kernel with one workgroup per window takes the list path too.  All agree with the oracle."""
+    import orbslam_in_practice_amd as oa
     from orbslam_in_practice_amd import synth
     ws = []
-    for seed in (61, 62):
+    for seed in (61, 62, 63, 64):
         w = synth.make_ba_window(seed, 100, 600)
         w["fixed"][:2] = 1
         q, t = w["gt_poses"][:, :4], w["gt_poses"][:, 4:]
-        X = w["gt_points"][0]
         rng = np.random.default_rng(seed)
-        have = set(w["cam_idx"][w["pt_idx"] == 0].tolist())
-        add_c, add_o = [], []
-        for c in range(100):
-            if c in have:
-                continue
-            qw, qx, qy, qz = q[c]
-            R = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)],
-                          [2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)],
-                          [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]])
-            pc = R @ X + t[c]
-            if pc[2] <= 0.1:
-                continue
-            add_c.append(c)
-            add_o.append([w["fx"] * pc[0] / pc[2] + w["cx"] + rng.normal(0, 1), w["fy"] * pc[1] / pc[2] + w["cy"] + rng.normal(0, 1)])
-        w["cam_idx"] = np.concatenate([w["cam_idx"], np.array(add_c, np.int32)])
-        w["pt_idx"] = np.concatenate([w["pt_idx"], np.zeros(len(add_c), np.int32)])
-        w["obs"] = np.concatenate([w["obs"], np.array(add_o).reshape(-1, 2)])
-        w["inv_sigma2"] = np.concatenate([w["inv_sigma2"], np.ones(len(add_c))])
-        assert (w["pt_idx"] == 0).sum() > 91          # k (k + 1) / 2 > 4096
+        for pid in (0, 7):          # two such points per window
+            X = w["gt_points"][pid]
+            have = set(w["cam_idx"][w["pt_idx"] == pid].tolist())
+            add_c, add_o = [], []
+            for c in range(100):
+                if c in have:
+                    continue
+                qw, qx, qy, qz = q[c]
+                R = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)],
+                              [2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)],
+                              [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]])
+                pc = R @ X + t[c]
+                if pc[2] <= 0.1:
+                    continue
+                add_c.append(c)
+                add_o.append([w["fx"] * pc[0] / pc[2] + w["cx"] + rng.normal(0, 1), w["fy"] * pc[1] / pc[2] + w["cy"] + rng.normal(0, 1)])
+            w["cam_idx"] = np.concatenate([w["cam_idx"], np.array(add_c, np.int32)])
+            w["pt_idx"] = np.concatenate([w["pt_idx"], np.full(len(add_c), pid, np.int32)])
+            w["obs"] = np.concatenate([w["obs"], np.array(add_o).reshape(-1, 2)])
+            w["inv_sigma2"] = np.concatenate([w["inv_sigma2"], np.ones(len(add_c))])
+            assert (w["pt_idx"] == pid).sum() > 91
         ws.append(w)
-    got = opt.solve_batch(ws, (5, 10))
-    for w, g in zip(ws, got):
-        ref = oracle.ba_solve(w, rounds=(5, 10))
-        _check_estimates(g, ref)
+    refs = [oracle.ba_solve(w, rounds=(5, 10)) for w in ws]
+    for force_team, want_team, sub in ((None, None, ws), ("1", 1, ws[:2]), (None, None, ws[:1])):
+        if force_team is None:
+            monkeypatch.delenv("ORBSLAM_AMD_BA_TEAM", raising=False)
+        else:
+            monkeypatch.setenv("ORBSLAM_AMD_BA_TEAM", force_team)
+        o = oa.Optimizer(max_cams=100, max_points=600, max_obs=8192, max_batch=4)
+        o.set_profiling(True)
+        got = o.solve_batch(sub, (5, 10))
+        team = o.iteration_ms()[2]
+        o.close()
+        if want_team is not None:
+            assert team == want_team          # fused kernel, one workgroup per window, per-block lists
+        else:
+            assert team > 1                   # teams and per-block lists, four windows or one
+        for g, r in zip(got, refs):
+            _check_estimates(g, r)
 
 
 @pytest.mark.parametrize("spare", [None, "-100", "0"])
