@@ -1842,8 +1842,12 @@ template <class SH> __device__ __forceinline__ void ba_ph_dinv(const BAWin &w, d
         }
         if (build) st[ST_QMAX] = 0.0;
     }
-    ba_phase_dinv<true>(w, D, I, lambda, threadIdx.x, BA_T);
-    ba_phase_ufactor(w, D, lambda, threadIdx.x, BA_T);
+    if (w.nchunks > 0) {
+        ba_phase_dinv<true>(w, D, I, lambda, threadIdx.x, BA_T);
+        ba_phase_ufactor(w, D, lambda, threadIdx.x, BA_T);
+    } else {
+        ba_phase_dinv<false>(w, D, I, lambda, threadIdx.x, BA_T);
+    }
 }
 __device__ __forceinline__ void ba_ph_chol(const BAWin &w, double *D, const int32_t *I, double *dyn, double *bad_flag) {
     double *st = D + w.st;
@@ -1864,7 +1868,7 @@ template <class SH> __device__ __forceinline__ void ba_ph_update(const BAWin &w,
     const double currentChi = st[ST_CHI];
     const bool ok2 = st[ST_OK2] != 0.0;
     int qmax = (int)st[ST_QMAX], budget = (int)st[ST_BUDGET];
-    double scale = ba_phase_backsub<true>(w, D, I, ok2, lambda, threadIdx.x, BA_T);
+    double scale = w.nchunks > 0 ? ba_phase_backsub<true>(w, D, I, ok2, lambda, threadIdx.x, BA_T) : ba_phase_backsub<false>(w, D, I, ok2, lambda, threadIdx.x, BA_T);
     __syncthreads();
     BATeam one;
     one.G = 1;
@@ -1995,8 +1999,11 @@ __global__ __launch_bounds__(BA_PH_T) void k_ba_ph_hll(BABufs bufs) {
 __global__ __launch_bounds__(BA_PH_T) void k_ba_ph_hpp(BABufs bufs) { /* one wavefront per camera */
     BA_PH_WINDOW
     if (ph != 0.0) return;
-    ba_phase_hpp<true>(w, D, I, B, blockIdx.y * (BA_PH_T / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), gridDim.y * (BA_PH_T / 64),
-                 threadIdx.x & 63);
+    const int gw = blockIdx.y * (BA_PH_T / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), gws = gridDim.y * (BA_PH_T / 64);
+    if (w.nchunks > 0)
+        ba_phase_hpp<true>(w, D, I, B, gw, gws, threadIdx.x & 63);  /* point chunks: 32-byte edge records */
+    else
+        ba_phase_hpp<false>(w, D, I, B, gw, gws, threadIdx.x & 63); /* per-block lists (long tracks): W itself */
 }
 /* single workgroup per window: the current chi2 from its partial sums, computeLambdaInit on the first iteration of a
    round, trial counter */
@@ -2029,8 +2036,12 @@ __global__ __launch_bounds__(BA_T) void k_ba_ph_prep(BABufs bufs) {
 __global__ __launch_bounds__(BA_PH_T) void k_ba_ph_dinv(BABufs bufs) {
     BA_PH_WINDOW
     if (ph == 2.0) return;
-    ba_phase_dinv<true>(w, D, I, D[w.st + ST_LAMBDA], blockIdx.y * BA_PH_T + threadIdx.x, gridDim.y * BA_PH_T);
-    ba_phase_ufactor(w, D, D[w.st + ST_LAMBDA], blockIdx.y * BA_PH_T + threadIdx.x, gridDim.y * BA_PH_T);
+    if (w.nchunks > 0) {
+        ba_phase_dinv<true>(w, D, I, D[w.st + ST_LAMBDA], blockIdx.y * BA_PH_T + threadIdx.x, gridDim.y * BA_PH_T);
+        ba_phase_ufactor(w, D, D[w.st + ST_LAMBDA], blockIdx.y * BA_PH_T + threadIdx.x, gridDim.y * BA_PH_T);
+    } else {
+        ba_phase_dinv<false>(w, D, I, D[w.st + ST_LAMBDA], blockIdx.y * BA_PH_T + threadIdx.x, gridDim.y * BA_PH_T);
+    }
     ba_phase_zero2(w, D, blockIdx.y * BA_PH_T + threadIdx.x, gridDim.y * BA_PH_T);
 }
 /* The Schur pass of the phase-kernel path: the window's point chunks are split over two groups of 256 threads,
@@ -2225,10 +2236,19 @@ __device__ __forceinline__ void ba_schur_part(const BAWin &w, double *D, const i
 __global__ __launch_bounds__(BA_SH_T) void k_ba_ph_schur2(BABufs bufs, int skip) {
     extern __shared__ __attribute__((aligned(16))) double ba_dyn[];
     BA_PH_WINDOW
-    if (ph == 2.0) return;
+    if (ph == 2.0 || w.nchunks <= 0) return;
     const int part = blockIdx.y, nparts = gridDim.y;
     const int nloop = (int)((int64_t)w.nchunks * (part + 1) / nparts) - (int)((int64_t)w.nchunks * part / nparts);
     ba_schur_part(w, D, I, ba_dyn, threadIdx.x, part, nparts, nloop, skip);
+}
+/* the Schur pass of a window whose points have LONG tracks (ba_window_chunkable): one owner per block walking the block's
+   contribution list, and per camera for g -- the team path's functions, strided over the workgroups of the window */
+__global__ __launch_bounds__(BA_T) void k_ba_ph_schur_lists(BABufs bufs) {
+    BA_PH_WINDOW
+    if (ph == 2.0 || w.nchunks > 0) return;
+    const int gw = blockIdx.y * BA_W + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), gws = gridDim.y * BA_W;
+    ba_schur_lists(w, D, I, gw, gws);
+    ba_g_lists(w, D, I, gw, gws);
 }
 __global__ __launch_bounds__(BA_T) void k_ba_ph_chol(BABufs bufs) {
     extern __shared__ __attribute__((aligned(16))) double ba_dyn[];
@@ -2242,7 +2262,11 @@ __global__ __launch_bounds__(BA_PH_T) void k_ba_ph_backsub(BABufs bufs) {
     BA_PH_WINDOW
     const int parts = ba_ph_parts_p(w.Np);
     if (ph == 2.0 || (int)blockIdx.y >= parts) return;
-    const double v = block_sum_n(ba_phase_backsub<true>(w, D, I, D[w.st + ST_OK2] != 0.0, D[w.st + ST_LAMBDA], blockIdx.y * BA_PH_T + threadIdx.x, parts * BA_PH_T), s, BA_PH_T / 64);
+    const bool ok2 = D[w.st + ST_OK2] != 0.0;
+    const double lam = D[w.st + ST_LAMBDA];
+    const double part_sum = w.nchunks > 0 ? ba_phase_backsub<true>(w, D, I, ok2, lam, blockIdx.y * BA_PH_T + threadIdx.x, parts * BA_PH_T)
+                                          : ba_phase_backsub<false>(w, D, I, ok2, lam, blockIdx.y * BA_PH_T + threadIdx.x, parts * BA_PH_T);
+    const double v = block_sum_n(part_sum, s, BA_PH_T / 64);
     if (threadIdx.x == 0) D[w.gred + PH_RED_SCALE + blockIdx.y] = v;
 }
 __global__ __launch_bounds__(BA_PH_T) void k_ba_ph_trial(BABufs bufs) {
@@ -2325,15 +2349,22 @@ __global__ __launch_bounds__(BA_T) void k_ba_ph_finish(BABufs bufs) {
             if (D[w.st + ST_HAVECHI] == 0.0) ba_ph_chi2(w, D, I, B, s);
             __syncthreads();
             ba_phase_hll(w, D, I, B, threadIdx.x, BA_T);
-            ba_phase_hpp<true>(w, D, I, B, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), BA_W, threadIdx.x & 63);
+            if (w.nchunks > 0)
+                ba_phase_hpp<true>(w, D, I, B, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), BA_W, threadIdx.x & 63);
+            else
+                ba_phase_hpp<false>(w, D, I, B, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), BA_W, threadIdx.x & 63);
             __syncthreads();
         }
         ba_ph_dinv(w, D, I, s);
         ba_phase_zero2(w, D, threadIdx.x, BA_T);
         __syncthreads();
-        { /* both parts of the Schur pass inside this workgroup: threads 0..255 part 0, 256..511 part 1, own LDS tiles */
+        if (w.nchunks > 0) { /* both parts of the Schur pass inside this workgroup: threads 0..255 part 0, 256..511 part 1, own LDS tiles */
             const int half = threadIdx.x / BA_SH_T;
             ba_schur_part(w, D, I, ba_dyn + half * BA_CHUNK_DOUBLES, threadIdx.x - half * BA_SH_T, half, 2, (w.nchunks + 1) / 2, 0);
+        } else { /* long tracks: per-block lists */
+            const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+            ba_schur_lists(w, D, I, wv, BA_W);
+            ba_g_lists(w, D, I, wv, BA_W);
         }
         __syncthreads();
         ba_ph_chol(w, D, I, ba_dyn, &s.bc[0]);
@@ -2413,12 +2444,19 @@ static int64_t BAWin::*const kScratchFields[] = {&BAWin::poses_t, &BAWin::pts_t,
  * 32 windows of 40 keyframes x 1500 points with tracks of 30) -- there the per-block lists win, whose owners walk ~1000
  * contributions each.  Measured on that shape, kernel ms per 32-window batch, teams + lists / phase kernels + chunks:
  * tracks of 8: 25.4 / 8.0, 12: 35.4 / 10.4, 15: 40.9 / 15.6, 18: 48.3 / 22.6, 22: 50.1 / 38.5, 26 (with 480 blocks per
- * chunk): 70.2 / 69.4, 30: 71.2 / 122.5.  So: chunks when no point is seen by more than BA_CHUNK_MAX_TRACK free
- * keyframes (and the mean does not exceed BA_CHUNK_MEAN_TRACK), lists otherwise. */
+ * chunk): 70.2 / 69.4, 30: 71.2 / 122.5.  With the lists as a phase kernel too (k_ba_ph_schur_lists), same shape, phase
+ * kernels + lists / phase kernels + chunks: tracks of 6: 6.7 / 7.3, 12: 10.2 / 10.5, 18: 16.6 / 22.8, 22: 23.0 / 38.9, 30:
+ * 32.5 / - : with 32 such windows W (83 .. 150 MB) stays in the Infinity Cache and the lists' re-reads are cheap; at 256
+ * windows of 100 x 5000 (1 GB of W) they are HBM traffic and the chunks win 41 to 94 ms.  So: chunks when no point is seen
+ * by more than BA_CHUNK_MAX_TRACK free keyframes and the mean track length is at most BA_CHUNK_MEAN_TRACK_CACHED (the
+ * batch's W fits the cache) or BA_CHUNK_MEAN_TRACK (it does not); lists otherwise. */
 #define BA_CHUNK_MAX_TRACK 22
-#define BA_CHUNK_MEAN_TRACK 22
-static bool ba_window_chunkable(const BAProblem *p) {
-    static const int mean_track = getenv("ORBSLAM_AMD_BA_MEAN_TRACK") ? atoi(getenv("ORBSLAM_AMD_BA_MEAN_TRACK")) : BA_CHUNK_MEAN_TRACK; /* (diagnostics) */
+#define BA_CHUNK_MEAN_TRACK 22       /* ... when the batch's W does not fit the Infinity Cache */
+#define BA_CHUNK_MEAN_TRACK_CACHED 12 /* ... when it does: lists are as good at short tracks and better beyond (below) */
+#define BA_CACHED_W_BYTES (192u << 20)
+static bool ba_window_chunkable(const BAProblem *p, int mean_track_limit) {
+    static const int forced = getenv("ORBSLAM_AMD_BA_MEAN_TRACK") ? atoi(getenv("ORBSLAM_AMD_BA_MEAN_TRACK")) : 0; /* (diagnostics) */
+    const int mean_track = forced > 0 ? forced : mean_track_limit;
     if (p->n_points <= 0 || (long)p->n_obs > (long)mean_track * p->n_points) return false;
     std::vector<int> deg(p->n_points, 0);
     for (int e = 0; e < p->n_obs; e++) {
@@ -2433,7 +2471,8 @@ static bool ba_window_chunkable(const BAProblem *p) {
  * several workgroups (or is too irregular for point chunks) -> per-block contribution lists; otherwise point
  * chunks for the LDS-staged Schur pass of the batch path. */
 static int stage_problem(const BAProblem *p, std::vector<double> &hO, std::vector<double> &hD, size_t &scratchD,
-                         std::vector<int32_t> &hI, std::vector<uint8_t> &hB, HostWin &hw, bool team) {
+                         std::vector<int32_t> &hI, std::vector<uint8_t> &hB, HostWin &hw, bool team,
+                         int mean_track_limit = BA_CHUNK_MEAN_TRACK) {
     if (!p || p->n_cams <= 0 || p->n_points < 0 || p->n_obs < 0 || !p->poses || !p->fixed ||
         (p->n_points && !p->points) || (p->n_obs && (!p->obs || !p->cam_idx || !p->pt_idx || !p->inv_sigma2)) ||
         p->n_rounds < 1 || p->n_rounds > 4)
@@ -2530,7 +2569,7 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hO, std::vecto
     for (int s1 = 0; s1 < Ncf; s1++)
         for (int bk = brow[s1]; bk < brow[s1 + 1]; bk++) bmirror[bk] = blk[(size_t)bcol[bk] * Ncf + s1];
     const int ncon = ccount[nnzb];
-    const bool chunked = !team && max_deg <= BA_CHUNK_E && Ncf > 0 && ba_window_chunkable(p);
+    const bool chunked = !team && max_deg <= BA_CHUNK_E && Ncf > 0 && ba_window_chunkable(p, mean_track_limit);
     /* ---- list path: per block, the edge pairs (a, b) of the points both cameras see ---- */
     std::vector<int> ce1, ce2;
     if (!chunked) {
@@ -2676,7 +2715,7 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hO, std::vecto
             chd.insert(chd.end(), d, d + BA_CH_DESC);
             p0 = p1;
         }
-        if (chunk_overflow) return stage_problem(p, hO, hD, scratchD, hI, hB, hw, true); /* nothing laid out yet */
+        if (chunk_overflow) return stage_problem(p, hO, hD, scratchD, hI, hB, hw, true, mean_track_limit); /* nothing laid out yet */
     }
     /* ---- lay out ---- */
     auto allocO = [&](size_t n) { /* outputs: downloaded */
@@ -2725,7 +2764,7 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hO, std::vecto
     w.Uf = chunked ? allocS((size_t)Np * 6) : 0;
     w.tu = chunked ? allocS((size_t)Np * 3) : 0;
     w.S2 = chunked ? allocS((size_t)nnzb * 36) : w.S; /* (never read when the window is not chunked) */
-    w.g2 = chunked ? allocS((size_t)Ncf * 6) : w.g;
+    w.g2 = allocS((size_t)Ncf * 6); /* (also for list windows: the Cholesky of the phase path adds g and g2) */
     w.Minv = allocS((size_t)Ncf * 36);
     w.x = allocS((size_t)Ncf * 6);
     w.xl = allocS(2);
@@ -3071,18 +3110,16 @@ static int ba_stage(BASolver *s, BAJob &J, const BAProblem *probs, BAResult *res
         const bool wanted = s->force_split == 1 || nwin >= BA_SPLIT_MIN_WINDOWS || (nwin >= BA_SPLIT_MIN_SMALL && maxE < BA_SPLIT_BIG_EDGES);
         if (wanted && s->force_split != 0 && s->force_team == 0 && s->solver == 1 && !any_stop && !getenv("ORBSLAM_AMD_BA_PROFILE") &&
             !getenv("ORBSLAM_AMD_BA_DEBUG")) {
-            /* ... and only when every window is one for point chunks (long tracks stay with teams and per-block lists) */
-            std::vector<uint8_t> okw(nwin, 0);
-            const int nt = std::max(1, std::min<int>(nwin, std::min<int>(16, (int)std::thread::hardware_concurrency())));
-            ba_parallel(nt, [&](int t) {
-                for (int i = t; i < nwin; i += nt) okw[i] = ba_window_chunkable(&probs[i]) ? 1 : 0;
-            });
-            bool all_ok = true;
-            for (int i = 0; i < nwin; i++) all_ok = all_ok && okw[i];
-            if (all_ok) J.team = 1;
+            J.team = 1; /* (stage_problem lays a window out in point chunks or, long tracks, in per-block lists: both run as
+                           phase kernels) */
         }
     }
     const bool team = J.team > 1;
+    /* point chunks or per-block lists for the windows of a batch that runs as phase kernels: with the batch's W inside the
+       Infinity Cache the lists are as good as chunks at short tracks and better beyond (ba_window_chunkable) */
+    size_t total_obs = 0;
+    for (int i = 0; i < nwin; i++) total_obs += (size_t)std::max(probs[i].n_obs, 0);
+    const int mean_limit = total_obs * 144 <= (size_t)BA_CACHED_W_BYTES ? BA_CHUNK_MEAN_TRACK_CACHED : BA_CHUNK_MEAN_TRACK;
     if ((int)s->pieces.size() < nwin) s->pieces.resize(nwin);
     std::vector<BAPiece> &pieces = s->pieces;
     const int nthr = std::max(1, std::min<int>(nwin, std::min<int>(16, (int)std::thread::hardware_concurrency())));
@@ -3094,7 +3131,7 @@ static int ba_stage(BASolver *s, BAJob &J, const BAProblem *probs, BAResult *res
             pc.I.clear();
             pc.B.clear();
             pc.scratch = 0;
-            pc.rc = stage_problem(&probs[i], pc.O, pc.D, pc.scratch, pc.I, pc.B, J.hw[i], team);
+            pc.rc = stage_problem(&probs[i], pc.O, pc.D, pc.scratch, pc.I, pc.B, J.hw[i], team, mean_limit);
         }
     });
     size_t nO = 0, nD = 0, nI = 0, nB = 0;
@@ -3213,7 +3250,7 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
     for (int i = 0; i < nwin && split; i++) {
         const BAWin &w = J.wins[i];
         const size_t need = (size_t)std::max(w.ch_pm, 0) * CH_LD + 2 * 16 * CH_LD + (((size_t)w.Ncf * 6 + 15) & ~(size_t)15);
-        if (w.nchunks <= 0 || w.ch_pm <= 0 || w.Ncf <= 0 || need > (size_t)dyn_doubles) split = false;
+        if (w.ch_pm <= 0 || w.Ncf <= 0 || need > (size_t)dyn_doubles) split = false;
         chol_doubles = std::max(chol_doubles, need);
     }
     if (s->force_split == 0) split = false;
@@ -3259,6 +3296,14 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
             maxC = std::max(maxC, J.wins[i].Nc);
         }
         const int partsE = ba_ph_parts_e(maxE), partsP = ba_ph_parts_p(maxP);
+        bool any_lists = false;
+        int max_nub = 0;
+        for (int i = 0; i < nwin; i++)
+            if (J.wins[i].nchunks <= 0) {
+                any_lists = true;
+                max_nub = std::max(max_nub, J.wins[i].nub);
+            }
+        const int parts_lists = std::max(1, std::min(16, (max_nub + 4 * BA_W - 1) / (4 * BA_W))); /* four blocks per wavefront and step */
         const int partsC = std::max(1, (maxC + BA_PH_T / 64 - 1) / (BA_PH_T / 64));
         int trial_seq = 0;
         for (int round = 0; round < P0.n_rounds; round++) {
@@ -3281,6 +3326,8 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
                          hipLaunchKernelGGL(k_ba_ph_schur2, dim3(nwin, 2), dim3(BA_SH_T), (size_t)BA_CHUNK_DOUBLES * 8, ks, bufs, schur_skip);
                      })))
                     return rc;
+                if (any_lists)
+                    if ((rc = timed(4, [&] { hipLaunchKernelGGL(k_ba_ph_schur_lists, dim3(nwin, parts_lists), dim3(BA_T), 0, ks, bufs); }))) return rc;
                 if ((rc = timed(5, [&] { hipLaunchKernelGGL(k_ba_ph_chol, dim3(nwin), dim3(BA_T), chol_doubles * 8, ks, bufs); }))) return rc;
                 if ((rc = timed(6, [&] { hipLaunchKernelGGL(k_ba_ph_backsub, gP, tb, 0, ks, bufs); }))) return rc;
                 if ((rc = timed(7, [&] { hipLaunchKernelGGL(k_ba_ph_trial, gE, tb, 0, ks, bufs); }))) return rc;

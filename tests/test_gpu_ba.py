@@ -383,8 +383,9 @@ def test_ba_more_than_256_free_cameras(oracle):
 def test_ba_point_seen_by_every_camera(oracle, monkeypatch):
     """two points per window observed by all 100 keyframes: 4851 contributions each to the reduced system, every one to
     another block -- nineteen times what a point chunk of the LDS-staged Schur pass holds.  Long tracks are what the
-    per-block lists are for (ba_window_chunkable): such windows keep teams and lists also in a batch, and the fused
-    kernel with one workgroup per window takes the list path too.  All agree with the oracle."""
+    per-block lists are for (ba_window_chunkable): in a batch such windows run as phase kernels with the list pass in
+    place of the chunked one, alone on a team, and the fused kernel with one workgroup per window takes the list path
+    too.  All agree with the oracle."""
     import orbslam_in_practice_amd as oa
     from orbslam_in_practice_amd import synth
     ws = []
@@ -416,7 +417,7 @@ def test_ba_point_seen_by_every_camera(oracle, monkeypatch):
             assert (w["pt_idx"] == pid).sum() > 91
         ws.append(w)
     refs = [oracle.ba_solve(w, rounds=(5, 10)) for w in ws]
-    for force_team, want_team, sub in ((None, None, ws), ("1", 1, ws[:2]), (None, None, ws[:1])):
+    for force_team, want_team, sub in ((None, 0, ws), ("1", 1, ws[:2]), (None, None, ws[:1])):
         if force_team is None:
             monkeypatch.delenv("ORBSLAM_AMD_BA_TEAM", raising=False)
         else:
@@ -427,9 +428,9 @@ def test_ba_point_seen_by_every_camera(oracle, monkeypatch):
         team = o.iteration_ms()[2]
         o.close()
         if want_team is not None:
-            assert team == want_team          # fused kernel, one workgroup per window, per-block lists
+            assert team == want_team          # 0: phase kernels with the list pass (four windows); 1: fused kernel, one workgroup per window
         else:
-            assert team > 1                   # teams and per-block lists, four windows or one
+            assert team > 1                   # one window: a team
         for g, r in zip(got, refs):
             _check_estimates(g, r)
 
