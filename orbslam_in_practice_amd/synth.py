@@ -163,3 +163,40 @@ def make_ba_window(seed, n_cams=50, n_points=2000, outlier_frac=0.05, fx=525.0, 
                 obs=np.array(obs, np.float64).reshape(-1, 2), cam_idx=np.array(cam_idx, np.int32),
                 pt_idx=np.array(pt_idx, np.int32), inv_sigma2=np.array(inv_s2, np.float64),
                 gt_poses=gt_poses, gt_points=pts, fx=fx, fy=fy, cx=cx, cy=cy)
+
+
+def _quat_R(q):
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def make_ba_window_long_tracks(seed, nc, npt, track):
+    """make_ba_window with every point observed by `track` consecutive keyframes (a real local map; the plain generator
+    stops at 10): the extra observations are projections of the ground truth + N(0, 1) pixels; two keyframes fixed."""
+    w = make_ba_window(seed, nc, npt, outlier_frac=0.02)
+    rng = np.random.default_rng(seed)
+    R = [_quat_R(q) for q in w["gt_poses"][:, :4]]
+    t = w["gt_poses"][:, 4:]
+    cam, pt, obs, info = [list(w[k]) for k in ("cam_idx", "pt_idx", "obs", "inv_sigma2")]
+    seen = {(int(c), int(p)) for c, p in zip(w["cam_idx"], w["pt_idx"])}
+    first = {}
+    for c, p in zip(w["cam_idx"], w["pt_idx"]):
+        first[int(p)] = min(first.get(int(p), nc), int(c))
+    for p in range(npt):
+        c0 = min(first.get(p, 0), max(nc - track, 0))
+        for c in range(c0, min(nc, c0 + track)):
+            if (c, p) in seen:
+                continue
+            pc = R[c] @ w["gt_points"][p] + t[c]
+            if pc[2] <= 0.1:
+                continue
+            cam.append(c)
+            pt.append(p)
+            obs.append([w["fx"] * pc[0] / pc[2] + w["cx"] + rng.normal(0, 1), w["fy"] * pc[1] / pc[2] + w["cy"] + rng.normal(0, 1)])
+            info.append(1.0)
+    w["cam_idx"], w["pt_idx"] = np.asarray(cam, np.int32), np.asarray(pt, np.int32)
+    w["obs"], w["inv_sigma2"] = np.asarray(obs, np.float64).reshape(-1, 2), np.asarray(info, np.float64)
+    w["fixed"][:2] = 1
+    return w

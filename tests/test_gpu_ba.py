@@ -469,3 +469,23 @@ def test_ba_phase_kernel_batch_path(oracle, monkeypatch, spare):
         assert _rel(s1["points"], got[i]["points"]) < 1e-6
         assert _rel(s1["poses"], got[i]["poses"]) < 1e-6
     o1.close()
+
+
+def test_ba_mixed_batch_of_chunk_and_list_windows(oracle):
+    """one batch through the phase kernels with both kinds of windows: short tracks (point chunks, 32-byte edge records, two-part
+    Schur pass) and long tracks (per-block lists, the list pass as a phase kernel): every window within 1e-5 of the oracle"""
+    import orbslam_in_practice_amd as oa
+    from orbslam_in_practice_amd import synth
+    ws = []
+    for i in range(4):
+        w = synth.make_ba_window(8100 + i, 20, 400)
+        w["fixed"][:2] = 1
+        ws.append(w)
+        ws.append(synth.make_ba_window_long_tracks(8200 + i, 20, 400, 16 if i % 2 else 26))
+    o = oa.Optimizer(max_cams=20, max_points=400, max_obs=16384, max_batch=len(ws))
+    o.set_profiling(True)
+    got = o.solve_batch(ws, (5, 10))
+    assert o.iteration_ms()[2] == 0          # phase kernels
+    o.close()
+    for w, g in zip(ws, got):
+        _check_estimates(g, oracle.ba_solve(w, rounds=(5, 10)), converged_ok=True)
