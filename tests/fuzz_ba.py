@@ -90,10 +90,13 @@ def run_batches(n_batches=2, seed=11, sample=3):
         for i in range(nwin):
             nc = int(rng.integers(3, 36))
             npt = int(rng.integers(30, 40 * nc + 40))
-            w = synth.make_ba_window(int(rng.integers(1 << 30)), nc, npt, outlier_frac=float(rng.choice([0.0, 0.05, 0.15])))
-            nfix = int(rng.integers(1, max(2, nc // 3)))
-            w["fixed"][:] = 0
-            w["fixed"][rng.permutation(nc)[:nfix]] = 1
+            if nc >= 14 and rng.integers(0, 4) == 0:   # a window with long tracks: staged as per-block lists, the list pass of the phase path
+                w = synth.make_ba_window_long_tracks(int(rng.integers(1 << 30)), nc, min(npt, 600), int(rng.integers(12, nc + 1)))
+            else:
+                w = synth.make_ba_window(int(rng.integers(1 << 30)), nc, npt, outlier_frac=float(rng.choice([0.0, 0.05, 0.15])))
+                nfix = int(rng.integers(1, max(2, nc // 3)))
+                w["fixed"][:] = 0
+                w["fixed"][rng.permutation(nc)[:nfix]] = 1
             ws.append(w)
         opt = oa.Optimizer(max_cams=40, max_points=2048, max_obs=40000, max_batch=nwin)
         opt.set_profiling(True)
@@ -105,7 +108,7 @@ def run_batches(n_batches=2, seed=11, sample=3):
             w, g = ws[i], got[i]
             ref = orc.ba_solve(w, rounds=rounds, robust=robust)
             same_its = g["iterations"] == ref["iterations"] or \
-                abs(g["chi2_final"] - ref["chi2_final"]) <= 1e-9 * max(ref["chi2_final"], 1e-30)
+                abs(g["chi2_final"] - ref["chi2_final"]) <= 1e-9 * ref["chi2_final"] + 1e-18 * ref["chi2_initial"]  # (noise-free: both at ~1e-27)
             ok = (same_its and np.array_equal(g["outlier"], ref["outlier"]) and
                   rel(g["points"], ref["points"]) < 1e-5 and rel(g["poses"][:, 4:], ref["poses"][:, 4:]) < 1e-5 and
                   abs(g["chi2_final"] - ref["chi2_final"]) <= 1e-6 * ref["chi2_final"] + 1e-18 * ref["chi2_initial"])  # (a noise-free window ends at 1e-27)
