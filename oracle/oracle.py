@@ -140,8 +140,11 @@ class OrbOracle:
     def extract(self, img, trig=TRIG_DET, cap=None):
         img = np.ascontiguousarray(img, np.uint8)
         h, w = img.shape
-        # per level the quadtree returns up to max(quota + 3, 4 * nIni) keypoints, nIni = round(W / H) roots (wide images)
-        cap = cap or (self.cfg.nfeatures + self.nlevels * (8 + 4 * (w // max(h, 1) + 2)) + 64)
+        # per level the quadtree returns up to max(quota + 3, 4 * nIni) keypoints, nIni = round(W / H) roots of the
+        # BORDERED level (W = width - 32, H = height - 32: a 1938 x 115 strip has 23, 26, 31 roots on its first levels)
+        if cap is None:
+            ws, hs = self.level_sizes(w, h)
+            cap = self.cfg.nfeatures + 64 + sum(8 + 4 * (max(int(a) - 32, 0) // max(int(b) - 32, 1) + 2) for a, b in zip(ws, hs))
         kps = np.zeros(cap, KP_DTYPE)
         desc = np.zeros((cap, 32), np.uint8)
         n = C.c_int32(0)

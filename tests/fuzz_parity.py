@@ -42,7 +42,11 @@ def run(n_cfg=30, seed=1, wild=False):
         got = e.extract_batch(frames) if nb > 1 else [e(frames[0])]
         feats = []
         for f, (k, d) in zip(frames, got):
-            ok, od = o.extract(f)
+            try:
+                ok, od = o.extract(f)
+            except RuntimeError as ex:  # a harness limit of the oracle wrapper, reported with the configuration that hit it
+                print("ORACLE ERROR cfg %d %dx%d nf %d scale %.1f nl %d th %d/%d batch %d: %s" % (c, w, h, nf, scale, nl, ini, mn, nb, ex))
+                raise
             same = np.array_equal(k, ok) and np.array_equal(d, od)
             bad += 0 if same else 1
             if not same:
@@ -126,7 +130,11 @@ def run(n_cfg=30, seed=1, wild=False):
                 print("MISMATCH sequence call %d: batch %d > max_batch was not refused with ORB_E_CAPACITY" % (c, nb))
             continue
         for f, (k, d) in zip(frames, got):
-            ok, od = o.extract(f)
+            try:
+                ok, od = o.extract(f)
+            except RuntimeError as ex:  # a harness limit of the oracle wrapper, reported with the configuration that hit it
+                print("ORACLE ERROR cfg %d %dx%d nf %d scale %.1f nl %d th %d/%d batch %d: %s" % (c, w, h, nf, scale, nl, ini, mn, nb, ex))
+                raise
             if not (np.array_equal(k, ok) and np.array_equal(d, od)):
                 sbad += 1
                 print("MISMATCH sequence call %d: %dx%d batch %d" % (c, w, h, nb))

@@ -154,7 +154,8 @@ def test_error_text_of_matcher_and_ba_reaches_orb_last_error():
     del k1, k2
 
 
-@pytest.mark.parametrize("w,h,nf,nl,nb", [(1346, 154, 100, 7, 3), (1008, 155, 100, 5, 1), (900, 120, 50, 4, 2)])
+@pytest.mark.parametrize("w,h,nf,nl,nb", [(1346, 154, 100, 7, 3), (1008, 155, 100, 5, 1), (900, 120, 50, 4, 2),
+                                          (1938, 115, 5, 3, 3)])  # 23 / 26 / 31 roots per level, 317 keypoints for a budget of 5
 def test_wide_frames_return_more_than_their_budget(oracle, w, h, nf, nl, nb):
     """nIni = round(W / H) quadtree roots (src/ORBextractor.cpp:493-534): a wide frame with a small feature budget
     returns up to 4 * nIni keypoints per level -- several times nfeatures.  The capacity bound has to follow the
