@@ -798,6 +798,34 @@ __device__ __forceinline__ void group16_reduce36(const double *acc, int l16, dou
     o1 = (h1 ? a6[4] : a6[1]) + xchg16<1>(h1 ? a6[1] : a6[4]);
     o2 = (h1 ? a6[5] : a6[2]) + xchg16<1>(h1 ? a6[2] : a6[5]);
 }
+/* the same over a group of 8 or 4 lanes (offsets 4, 2, 1 / 2, 1): 8 lanes -- 36 padded to 48, lane q ends up with the
+ * totals of entries 6q .. 6q+5 (lanes 6, 7: padding), 24 + 12 + 6 = 42 exchanges; 4 lanes -- lane q holds entries
+ * 9q .. 9q+8, 18 + 9 = 27 exchanges.  A (block, chunk) pair's list is 10 contributions long on average, so the narrower
+ * group idles less; BA_SG picks the width of the phase-kernel Schur pass. */
+#define BA_SG 4
+#define BA_SG_OUT (BA_SG == 8 ? 6 : 9)
+__device__ __forceinline__ void group_reduce36(const double *acc, int lg, double *o) {
+#if BA_SG == 8
+    double a24[24], a12[12];
+    const bool h4 = lg & 4, h2 = lg & 2, h1 = lg & 1;
+#pragma unroll
+    for (int i = 0; i < 24; i++) {
+        const double lo = acc[i], hi = (24 + i < 36) ? acc[24 + i] : 0.0;
+        a24[i] = (h4 ? hi : lo) + xchg16<4>(h4 ? lo : hi);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) a12[i] = (h2 ? a24[12 + i] : a24[i]) + xchg16<2>(h2 ? a24[i] : a24[12 + i]);
+#pragma unroll
+    for (int i = 0; i < 6; i++) o[i] = (h1 ? a12[6 + i] : a12[i]) + xchg16<1>(h1 ? a12[i] : a12[6 + i]);
+#else
+    double a18[18];
+    const bool h2 = lg & 2, h1 = lg & 1;
+#pragma unroll
+    for (int i = 0; i < 18; i++) a18[i] = (h2 ? acc[18 + i] : acc[i]) + xchg16<2>(h2 ? acc[i] : acc[18 + i]);
+#pragma unroll
+    for (int i = 0; i < 9; i++) o[i] = (h1 ? a18[9 + i] : a18[i]) + xchg16<1>(h1 ? a18[i] : a18[9 + i]);
+#endif
+}
 
 __device__ __noinline__ void ba_schur_chunked(const BAWin &w, double *D, const int32_t *I, double *ba_dyn, int debug) {
 #pragma clang fp contract(fast) /* the block products as FMAs: half the f64 instructions; estimates are compared at 1e-5 */
@@ -1927,6 +1955,19 @@ template <class SH> __device__ __forceinline__ void ba_ph_update(const BAWin &w,
     const double ph = D[w.st + ST_PH];      \
     (void)B;                                \
     (void)I;
+/* the same with the window's descriptor COPIED: its fields are then read once, at kernel entry and through the scalar
+   cache, and live in scalar registers.  Through the reference every use of a field after a store or a barrier is a fresh
+   (vector) load from memory -- the compiler cannot know that no store reaches the descriptor -- and the address of
+   nearly every load of a phase kernel hangs on one.  Only for kernels whose callees are all inlined (a non-inlined
+   callee would take the copy through scratch memory). */
+#define BA_PH_WINDOW_COPY                   \
+    const BAWin w = bufs.wins[blockIdx.x];  \
+    double *D = bufs.D;                     \
+    const int32_t *I = bufs.I;              \
+    const uint8_t *B = bufs.B;              \
+    const double ph = D[w.st + ST_PH];      \
+    (void)B;                                \
+    (void)I;
 #define BA_PH_T 256 /* threads per workgroup of the streaming phase kernels */
 enum { PH_RED_CHI = 0, PH_RED_SCALE = BA_GMAX, PH_RED_TRIAL = 2 * BA_GMAX }; /* partial-sum rows in gred */
 /* parts that SUM over a window's edges / points: a function of the window alone, so that its arithmetic (the order of
@@ -1985,19 +2026,19 @@ __device__ __forceinline__ double ba_ph_chi2_part(const BAWin &w, double *D, con
 
 __global__ __launch_bounds__(BA_PH_T) void k_ba_ph_chi2(BABufs bufs) {
     __shared__ BARed s;
-    BA_PH_WINDOW
+    BA_PH_WINDOW_COPY
     const int parts = ba_ph_parts_e(w.E);
     if (ph != 0.0 || D[w.st + ST_HAVECHI] != 0.0 || (int)blockIdx.y >= parts) return;
     const double v = block_sum_n(ba_ph_chi2_part(w, D, I, B, w.poses, w.pts, w.err, blockIdx.y * BA_PH_T + threadIdx.x, parts * BA_PH_T), s, BA_PH_T / 64);
     if (threadIdx.x == 0) D[w.gred + PH_RED_CHI + blockIdx.y] = v;
 }
 __global__ __launch_bounds__(BA_PH_T) void k_ba_ph_hll(BABufs bufs) {
-    BA_PH_WINDOW
+    BA_PH_WINDOW_COPY
     if (ph != 0.0) return;
     ba_phase_hll(w, D, I, B, blockIdx.y * BA_PH_T + threadIdx.x, gridDim.y * BA_PH_T);
 }
 __global__ __launch_bounds__(BA_PH_T) void k_ba_ph_hpp(BABufs bufs) { /* one wavefront per camera */
-    BA_PH_WINDOW
+    BA_PH_WINDOW_COPY
     if (ph != 0.0) return;
     const int gw = blockIdx.y * (BA_PH_T / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), gws = gridDim.y * (BA_PH_T / 64);
     if (w.nchunks > 0)
@@ -2034,7 +2075,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_ph_prep(BABufs bufs) {
     }
 }
 __global__ __launch_bounds__(BA_PH_T) void k_ba_ph_dinv(BABufs bufs) {
-    BA_PH_WINDOW
+    BA_PH_WINDOW_COPY
     if (ph == 2.0) return;
     if (w.nchunks > 0) {
         ba_phase_dinv<true>(w, D, I, D[w.st + ST_LAMBDA], blockIdx.y * BA_PH_T + threadIdx.x, gridDim.y * BA_PH_T);
@@ -2070,29 +2111,53 @@ __device__ __forceinline__ void ba_schur_part(const BAWin &w, double *D, const i
     int32_t *sB = sC + BA_CHUNK_C;
     int32_t *sBS = sB + BA_CHUNK_B;
     int32_t *sG = sBS + BA_CHUNK_B + 8;
-    const int grp = tid >> 4, l16 = tid & 15;
-    for (int it = 0; it < nloop; it++) {
+    const int grp = tid >> 4, l16 = tid & 15; /* g: 16 lanes per camera */
+    const int grpS = tid / BA_SG, lS = tid % BA_SG; /* S: BA_SG lanes per block */
+    /* A chunk's loads form a chain of three round trips -- its descriptor, the camera / point index of each edge, the
+       camera rotation and the point's factor gathered through those -- and the chain, not the bytes, is what the load
+       phase costs (5.8 of the 15.7 us a chunk takes).  The descriptor is therefore fetched TWO chunks ahead (uniform:
+       scalar registers) and the edge indices ONE chunk ahead (six registers per thread), both landing during the block
+       products, so that everything a chunk needs goes out in one round trip. */
+    constexpr int EPT = (BA_CHUNK_E + BA_SH_T - 1) / BA_SH_T;
+    struct ChDesc { int e0, ne, p0, npnt, cb0, ncb, cg0, ncg, c0, nc, g0, ng; };
+    auto load_desc = [&](int it) {
         const int ch = ch0 + it;
         const bool live = ch < ch1;
         const int32_t *cd = I + w.ch_desc + (live ? ch : ch0) * BA_CH_DESC;
-        const int e0 = cd[0], ne = live ? cd[1] - cd[0] : 0, p0 = cd[2], npnt = live ? cd[3] - cd[2] : 0, cb0 = cd[4], ncb = live ? cd[5] - cd[4] : 0;
-        const int cg0 = cd[6], ncg = live ? cd[7] - cd[6] : 0, c0 = cd[8], nc = live ? cd[9] : 0, g0 = cd[10], ng = live ? cd[11] : 0;
+        ChDesc d;
+        d.e0 = cd[0], d.ne = live ? cd[1] - cd[0] : 0, d.p0 = cd[2], d.npnt = live ? cd[3] - cd[2] : 0, d.cb0 = cd[4], d.ncb = live ? cd[5] - cd[4] : 0;
+        d.cg0 = cd[6], d.ncg = live ? cd[7] - cd[6] : 0, d.c0 = cd[8], d.nc = live ? cd[9] : 0, d.g0 = cd[10], d.ng = live ? cd[11] : 0;
+        return d;
+    };
+    auto load_idx = [&](const ChDesc &d, int32_t *cam, int32_t *pt, int32_t *cg) {
+#pragma unroll
+        for (int k = 0; k < EPT; k++) {
+            const int el = tid + k * BA_SH_T;
+            cam[k] = I[w.cam + d.e0 + (el < d.ne ? el : 0)];
+            pt[k] = el < d.ne ? I[w.pt + d.e0 + el] - d.p0 : 0;
+            cg[k] = el < d.ng ? I[w.cg_edge + d.g0 + el] : 0;
+        }
+    };
+    ChDesc dcur = load_desc(0), dnext = load_desc(1);
+    int32_t rCam[EPT], rP[EPT], rG[EPT];
+    load_idx(dcur, rCam, rP, rG);
+    for (int it = 0; it < nloop; it++) {
+        const int e0 = dcur.e0, ne = dcur.ne, p0 = dcur.p0, npnt = dcur.npnt, cb0 = dcur.cb0, ncb = dcur.ncb;
+        const int cg0 = dcur.cg0, ncg = dcur.ncg, c0 = dcur.c0, nc = dcur.nc, g0 = dcur.g0, ng = dcur.ng;
+        const ChDesc dafter = load_desc(it + 2);
+        int32_t nCam[EPT], nP[EPT], nG[EPT];
         { /* every load of the chunk issued before the first LDS write */
-            constexpr int TPT = (BA_CHUNK_P * 3 + BA_SH_T - 1) / BA_SH_T,
-                          EPT = (BA_CHUNK_E + BA_SH_T - 1) / BA_SH_T, CPT = (BA_CHUNK_C + BA_SH_T - 1) / BA_SH_T,
+            constexpr int TPT = (BA_CHUNK_P * 3 + BA_SH_T - 1) / BA_SH_T, CPT = (BA_CHUNK_C + BA_SH_T - 1) / BA_SH_T,
                           BPT = (BA_CHUNK_B + 1 + BA_SH_T - 1) / BA_SH_T;
             double2 rR[EPT][2];
             double rT[TPT];
-            int32_t rCam[EPT], rP[EPT], rG[EPT], rC[CPT], rB[BPT], rBS[BPT];
+            int32_t rC[CPT], rB[BPT], rBS[BPT];
 #pragma unroll
             for (int k = 0; k < EPT; k++) {
                 const int el = tid + k * BA_SH_T;
                 const double2 *rc = (const double2 *)(D + w.W + (int64_t)(e0 + (el < ne ? el : 0)) * 4);
                 rR[k][0] = rc[0];
                 rR[k][1] = rc[1];
-                rCam[k] = I[w.cam + e0 + (el < ne ? el : 0)];
-                rP[k] = el < ne ? I[w.pt + e0 + el] - p0 : 0;
-                rG[k] = el < ng ? I[w.cg_edge + g0 + el] : 0;
             }
 #pragma unroll
             for (int k = 0; k < TPT; k++) rT[k] = tid + k * BA_SH_T < npnt * 3 ? D[w.tu + (int64_t)p0 * 3 + tid + k * BA_SH_T] : 0.0;
@@ -2111,6 +2176,7 @@ __device__ __forceinline__ void ba_schur_part(const BAWin &w, double *D, const i
 #pragma unroll
                 for (int i = 0; i < 6; i++) rU[k][i] = D[w.Uf + (int64_t)(p0 + rP[k]) * 6 + i];
             }
+            load_idx(dnext, nCam, nP, nG); /* the next chunk's indices, behind this chunk's loads */
 #pragma unroll
             for (int k = 0; k < EPT; k++) { /* the W tile: one edge per thread, rebuilt from its record */
                 const int el = tid + k * BA_SH_T;
@@ -2145,40 +2211,44 @@ __device__ __forceinline__ void ba_schur_part(const BAWin &w, double *D, const i
             }
         }
         __syncthreads();
-        /* blocks: group g takes blocks g, g + 16, ... of the chunk's list (sorted heaviest first on the host); the
-           block's current value is fetched one pair ahead */
-        /* current value of entries 3 * l16 .. of a block: from memory, or -- FIRST touch by this part -- what the block
-           starts at: Hpp + lambda I for a diagonal block of part 0, zero otherwise */
-        auto block_value = [&](int raw, double *&ptr, double &v0, double &v1, double &v2) {
-            const int bk = raw & BA_BLK_MASK, e3 = (l16 < 12 ? l16 : 0) * 3;
-            ptr = D + So + (int64_t)bk * 36 + e3;
+        /* blocks: group g (BA_SG lanes) takes blocks g, g + 256 / BA_SG, ... of the chunk's list (sorted heaviest first on
+           the host); the block's current value is fetched one pair ahead */
+        /* current value of this lane's BA_SG_OUT entries of a block: from memory, or -- FIRST touch by this part -- what
+           the block starts at: Hpp + lambda I for a diagonal block of part 0, zero otherwise */
+        const int e0S = (lS * BA_SG_OUT < 36 ? lS : 0) * BA_SG_OUT;
+        auto block_value = [&](int raw, double *&ptr, double *v) {
+            const int bk = raw & BA_BLK_MASK;
+            ptr = D + So + (int64_t)bk * 36 + e0S;
             if (!(raw & BA_BLK_FIRST)) {
-                v0 = ptr[0];
-                v1 = ptr[1];
-                v2 = ptr[2];
+#pragma unroll
+                for (int i = 0; i < BA_SG_OUT; i++) v[i] = ptr[i];
             } else if (part == 0 && (raw & BA_BLK_DIAG)) {
-                const double *Hd = D + w.Hpp + (int64_t)I[w.blk_rowid + bk] * 36 + e3;
-                v0 = Hd[0] + (e3 % 7 == 0 ? lambda : 0.0);
-                v1 = Hd[1] + ((e3 + 1) % 7 == 0 ? lambda : 0.0);
-                v2 = Hd[2] + ((e3 + 2) % 7 == 0 ? lambda : 0.0);
+                const double *Hd = D + w.Hpp + (int64_t)I[w.blk_rowid + bk] * 36 + e0S;
+#pragma unroll
+                for (int i = 0; i < BA_SG_OUT; i++) v[i] = Hd[i] + ((e0S + i) % 7 == 0 ? lambda : 0.0);
             } else {
-                v0 = v1 = v2 = 0.0;
+#pragma unroll
+                for (int i = 0; i < BA_SG_OUT; i++) v[i] = 0.0;
             }
         };
-        int u = (skip & 16) ? ncb : grp;
+        int u = (skip & 16) ? ncb : grpS;
         double *Sb = nullptr;
-        double sb0 = 0, sb1 = 0, sb2 = 0;
-        if (u < ncb) block_value(sB[u], Sb, sb0, sb1, sb2);
-        for (; u < ncb; u += BA_SH_T / 16) {
+        double sb[BA_SG_OUT];
+#pragma unroll
+        for (int i = 0; i < BA_SG_OUT; i++) sb[i] = 0.0;
+        if (u < ncb) block_value(sB[u], Sb, sb);
+        for (; u < ncb; u += BA_SH_T / BA_SG) {
             const int k0 = sBS[u], k1 = sBS[u + 1];
-            const int un = u + BA_SH_T / 16;
+            const int un = u + BA_SH_T / BA_SG;
             double *Sn = Sb;
-            double sn0 = 0, sn1 = 0, sn2 = 0;
-            if (un < ncb) block_value(sB[un], Sn, sn0, sn1, sn2);
+            double sn[BA_SG_OUT];
+#pragma unroll
+            for (int i = 0; i < BA_SG_OUT; i++) sn[i] = 0.0;
+            if (un < ncb) block_value(sB[un], Sn, sn);
             double acc[36];
 #pragma unroll
             for (int i = 0; i < 36; i++) acc[i] = 0.0;
-            for (int k = (skip & 256) ? k1 : k0 + l16; k < k1; k += 16) {
+            for (int k = (skip & 256) ? k1 : k0 + lS; k < k1; k += BA_SG) {
                 const uint32_t ab = (uint32_t)sC[k];
                 const double *Za = sW + (ab & 511) * 18, *Zb = sW + ((ab >> 9) & 511) * 18;
                 double y[18], ww[18];
@@ -2192,17 +2262,15 @@ __device__ __forceinline__ void ba_schur_part(const BAWin &w, double *D, const i
                     for (int c = 0; c < 6; c++)
                         acc[r * 6 + c] += y[r * 3] * ww[c * 3] + y[r * 3 + 1] * ww[c * 3 + 1] + y[r * 3 + 2] * ww[c * 3 + 2];
             }
-            double d0, d1, d2;
-            group16_reduce36(acc, l16, d0, d1, d2); /* lane q now holds the totals of entries 3q .. 3q+2 */
-            if (l16 < 12) {
-                Sb[0] = sb0 - d0;
-                Sb[1] = sb1 - d1;
-                Sb[2] = sb2 - d2;
+            double d[BA_SG_OUT];
+            group_reduce36(acc, lS, d); /* lane q now holds the totals of entries q * BA_SG_OUT .. */
+            if (lS * BA_SG_OUT < 36) {
+#pragma unroll
+                for (int i = 0; i < BA_SG_OUT; i++) Sb[i] = sb[i] - d[i];
             }
             Sb = Sn;
-            sb0 = sn0;
-            sb1 = sn1;
-            sb2 = sn2;
+#pragma unroll
+            for (int i = 0; i < BA_SG_OUT; i++) sb[i] = sn[i];
         }
         /* g: group g takes cameras g, g + 16, ... of the chunk */
         for (int u2 = (skip & 64) ? ncg : grp; u2 < ncg; u2 += BA_SH_T / 16) {
@@ -2231,11 +2299,15 @@ __device__ __forceinline__ void ba_schur_part(const BAWin &w, double *D, const i
             }
         }
         __syncthreads(); /* the next chunk overwrites the LDS tiles and may touch the same blocks */
+        dcur = dnext;
+        dnext = dafter;
+#pragma unroll
+        for (int k = 0; k < EPT; k++) rCam[k] = nCam[k], rP[k] = nP[k], rG[k] = nG[k];
     }
 }
-__global__ __launch_bounds__(BA_SH_T) void k_ba_ph_schur2(BABufs bufs, int skip) {
+__global__ __launch_bounds__(BA_SH_T) __attribute__((amdgpu_waves_per_eu(2))) void k_ba_ph_schur2(BABufs bufs, int skip) {
     extern __shared__ __attribute__((aligned(16))) double ba_dyn[];
-    BA_PH_WINDOW
+    BA_PH_WINDOW_COPY
     if (ph == 2.0 || w.nchunks <= 0) return;
     const int part = blockIdx.y, nparts = gridDim.y;
     const int nloop = (int)((int64_t)w.nchunks * (part + 1) / nparts) - (int)((int64_t)w.nchunks * part / nparts);
@@ -2259,7 +2331,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_ph_chol(BABufs bufs) {
 }
 __global__ __launch_bounds__(BA_PH_T) void k_ba_ph_backsub(BABufs bufs) {
     __shared__ BARed s;
-    BA_PH_WINDOW
+    BA_PH_WINDOW_COPY
     const int parts = ba_ph_parts_p(w.Np);
     if (ph == 2.0 || (int)blockIdx.y >= parts) return;
     const bool ok2 = D[w.st + ST_OK2] != 0.0;
@@ -2271,7 +2343,7 @@ __global__ __launch_bounds__(BA_PH_T) void k_ba_ph_backsub(BABufs bufs) {
 }
 __global__ __launch_bounds__(BA_PH_T) void k_ba_ph_trial(BABufs bufs) {
     __shared__ BARed s;
-    BA_PH_WINDOW
+    BA_PH_WINDOW_COPY
     const int parts = ba_ph_parts_e(w.E);
     if (ph == 2.0 || (int)blockIdx.y >= parts) return;
     const double v = block_sum_n(ba_ph_chi2_part(w, D, I, B, w.poses_t, w.pts_t, w.err_t, blockIdx.y * BA_PH_T + threadIdx.x, parts * BA_PH_T), s, BA_PH_T / 64);
