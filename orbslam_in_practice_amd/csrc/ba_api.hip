@@ -2134,7 +2134,9 @@ __device__ __forceinline__ void ba_schur_part(const BAWin &w, double *D, const i
         for (int k = 0; k < EPT; k++) {
             const int el = tid + k * BA_SH_T;
             cam[k] = I[w.cam + d.e0 + (el < d.ne ? el : 0)];
-            pt[k] = el < d.ne ? I[w.pt + d.e0 + el] - d.p0 : 0;
+            pt[k] = el < d.ne ? I[w.pt + d.e0 + el] : d.p0; /* the point's index in the WINDOW: arithmetic on a guarded load
+                                                               makes the compiler wait for it inside the guard -- a
+                                                               round trip in the middle of the load sequence */
             cg[k] = el < d.ng ? I[w.cg_edge + d.g0 + el] : 0;
         }
     };
@@ -2166,7 +2168,7 @@ __device__ __forceinline__ void ba_schur_part(const BAWin &w, double *D, const i
 #pragma unroll
             for (int k = 0; k < BPT; k++) {
                 rB[k] = tid + k * BA_SH_T < ncb ? I[w.cb_blk + cb0 + tid + k * BA_SH_T] : 0;
-                rBS[k] = tid + k * BA_SH_T <= ncb ? I[w.cb_start + cb0 + tid + k * BA_SH_T] - c0 : 0;
+                rBS[k] = tid + k * BA_SH_T <= ncb ? I[w.cb_start + cb0 + tid + k * BA_SH_T] : c0; /* (- c0 at the LDS write) */
             }
             double rRot[EPT][9], rU[EPT][6];
 #pragma unroll
@@ -2174,7 +2176,7 @@ __device__ __forceinline__ void ba_schur_part(const BAWin &w, double *D, const i
 #pragma unroll
                 for (int i = 0; i < 9; i++) rRot[k][i] = D[w.Rc + (int64_t)rCam[k] * 9 + i];
 #pragma unroll
-                for (int i = 0; i < 6; i++) rU[k][i] = D[w.Uf + (int64_t)(p0 + rP[k]) * 6 + i];
+                for (int i = 0; i < 6; i++) rU[k][i] = D[w.Uf + (int64_t)rP[k] * 6 + i];
             }
             load_idx(dnext, nCam, nP, nG); /* the next chunk's indices, behind this chunk's loads */
 #pragma unroll
@@ -2194,7 +2196,7 @@ __device__ __forceinline__ void ba_schur_part(const BAWin &w, double *D, const i
                     }
 #pragma unroll
                     for (int i = 0; i < 9; i++) ((double2 *)(sW + el * 18))[i] = double2{Z[2 * i], Z[2 * i + 1]};
-                    sP[el] = rP[k];
+                    sP[el] = rP[k] - p0;
                     sG[el] = rG[k];
                 }
             }
@@ -2207,7 +2209,7 @@ __device__ __forceinline__ void ba_schur_part(const BAWin &w, double *D, const i
 #pragma unroll
             for (int k = 0; k < BPT; k++) {
                 if (tid + k * BA_SH_T < BA_CHUNK_B) sB[tid + k * BA_SH_T] = rB[k];
-                if (tid + k * BA_SH_T <= BA_CHUNK_B) sBS[tid + k * BA_SH_T] = rBS[k];
+                if (tid + k * BA_SH_T <= BA_CHUNK_B) sBS[tid + k * BA_SH_T] = rBS[k] - c0;
             }
         }
         __syncthreads();
@@ -2272,7 +2274,8 @@ __device__ __forceinline__ void ba_schur_part(const BAWin &w, double *D, const i
 #pragma unroll
             for (int i = 0; i < BA_SG_OUT; i++) sb[i] = sn[i];
         }
-        /* g: group g takes cameras g, g + 16, ... of the chunk */
+        /* g: group g takes cameras g, g + 16, ... of the chunk (16 lanes per camera; 4-lane groups -- fewer sequential
+           read-modify-writes of g per group -- measured slower: 13.4 against 11.7 ms) */
         for (int u2 = (skip & 64) ? ncg : grp; u2 < ncg; u2 += BA_SH_T / 16) {
             const int sl = I[w.cg_slot + cg0 + u2];
             const int k0 = I[w.cg_start + cg0 + u2] - g0, k1 = I[w.cg_start + cg0 + u2 + 1] - g0;
