@@ -1654,7 +1654,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
         } else {
         /* ---- PCG on S x = g ---- */
         double xi[3] = {0, 0, 0}, ri[3], zi[3], pi[3]; /* each thread owns rows tid, tid+BA_T, tid+2*BA_T */
-        double rz_loc = 0, gg_loc = 0;
+        double rz_loc = 0;
         __syncthreads();
         for (int q = 0; q < 3; q++) {
             const int i = tid + q * BA_T;
@@ -1675,7 +1675,6 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
             }
             pi[q] = zi[q];
             rz_loc += ri[q] * zi[q];
-            gg_loc += ri[q] * ri[q];
         }
         double rz = block_sum(rz_loc, s);
         const double rz0 = rz;
@@ -2145,7 +2144,7 @@ __device__ __forceinline__ void ba_schur_part(const BAWin &w, double *D, const i
     load_idx(dcur, rCam, rP, rG);
     for (int it = 0; it < nloop; it++) {
         const int e0 = dcur.e0, ne = dcur.ne, p0 = dcur.p0, npnt = dcur.npnt, cb0 = dcur.cb0, ncb = dcur.ncb;
-        const int cg0 = dcur.cg0, ncg = dcur.ncg, c0 = dcur.c0, nc = dcur.nc, g0 = dcur.g0, ng = dcur.ng;
+        const int cg0 = dcur.cg0, ncg = dcur.ncg, c0 = dcur.c0, nc = dcur.nc, g0 = dcur.g0;
         const ChDesc dafter = load_desc(it + 2);
         int32_t nCam[EPT], nP[EPT], nG[EPT];
         { /* every load of the chunk issued before the first LDS write */
