@@ -606,16 +606,8 @@ __device__ __noinline__ bool ba_chol_solve(const BAWin &w, double *D, const int3
         }
         if (bad && lane == 0) bad_flag[0] = 1.0;
     };
-    bool diag_done = false; /* uniform: the look-ahead of the previous step has factorised this step's diagonal tile */
-    for (int kb = 0; kb < nb; kb++) {
-        const int m = elast[kb] - kb; /* tile rows below the diagonal that reach column kb */
-        if (!diag_done) {
-            if (wave == 0) factor_diag(kb, false);
-            __syncthreads();
-        }
-        diag_done = false;
-        CH_STAMP(2)
-        /* panel: L_i = A_i * L11^-T */
+    /* panel of column kb: L_i = A_i * L11^-T for the m tile rows below the diagonal that reach the column */
+    auto panel = [&](int kb, int m) {
         if (g_chol_scalar) {
             for (int e = tid; e < m * 256; e += BA_T) {
                 const int bi = e >> 8, row = (e >> 4) & 15, col = e & 15;
@@ -629,7 +621,8 @@ __device__ __noinline__ bool ba_chol_solve(const BAWin &w, double *D, const int3
                 const int bi = e >> 8, row = (e >> 4) & 15, col = e & 15;
                 A[(int64_t)((kb + 1 + bi) * 16 + row) * np + kb * 16 + col] = P[(bi * 16 + row) * CH_LD + col];
             }
-        } else
+            return;
+        }
         for (int bi = wave; bi < m; bi += BA_W) {
             const int gi = kb + 1 + bi;
             v4d acc = {0.0, 0.0, 0.0, 0.0};
@@ -646,64 +639,95 @@ __device__ __noinline__ bool ba_chol_solve(const BAWin &w, double *D, const int3
                 P[(bi * 16 + row) * CH_LD + col] = acc[r];
             }
         }
-        __syncthreads();
-        CH_STAMP(3)
-        /* trailing update: A[i][j] -= L_i L_j^T for kb < j <= i.  LOOK-AHEAD (AHEAD: one window in flight, its matrix
-           resident in L2): the first tile of the update is the next step's diagonal tile; the wavefront that updates it
-           keeps it (through `sd`: the accumulator layout is not the row-per-lane layout of the factorisation) and
-           factorises it at once, while the other seven wavefronts finish the update -- the sequential chain of the
-           diagonal tile, half of a solve, runs beside the only other phase that needs neither its result nor `sl`:
-           Cholesky 5.3 -> 4.6 ms of a 100 x 5000 window's solve.  With 256 windows in flight the tile's
-           read-modify-write goes to HBM and lands ON the chain, and the second inlined copy of the (several thousand
-           instructions long) tile factorisation costs more than it saves: 8.7 -> 10.2 ms per batch, so the batch
-           instantiation is compiled without it. */
-        const int ntile = m * (m + 1) / 2;
-        auto update_tile = [&](int t, bool keep) {
-            int ii = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-            while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
-            while (ii * (ii + 1) / 2 > t) ii--;
-            const int jj = t - ii * (ii + 1) / 2;
-            const int gi = kb + 1 + ii, gj = kb + 1 + jj;
-            double *C = A + (int64_t)(gi * 16 + (lane >> 4)) * np + gj * 16 + (lane & 15);
-            v4d c4;
+    };
+    /* trailing update: A[i][j] -= L_i L_j^T for kb < j <= i, tile t of the m (m + 1) / 2; `keep`: the tile (the NEXT
+       step's diagonal tile) goes to `sd` instead of memory */
+    auto update_tile = [&](int kb, int t, bool keep) {
+        int ii = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
+        while (ii * (ii + 1) / 2 > t) ii--;
+        const int jj = t - ii * (ii + 1) / 2;
+        const int gi = kb + 1 + ii, gj = kb + 1 + jj;
+        double *C = A + (int64_t)(gi * 16 + (lane >> 4)) * np + gj * 16 + (lane & 15);
+        v4d c4;
 #pragma unroll
-            for (int r = 0; r < 4; r++) c4[r] = C[(int64_t)4 * r * np];
+        for (int r = 0; r < 4; r++) c4[r] = C[(int64_t)4 * r * np];
 #pragma unroll
-            for (int s4 = 0; s4 < 4; s4++) {
-                const double a = -P[(ii * 16 + (lane & 15)) * CH_LD + 4 * s4 + (lane >> 4)];
-                const double b = P[(jj * 16 + (lane & 15)) * CH_LD + 4 * s4 + (lane >> 4)];
-                c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c4, 0, 0, 0);
-            }
-            if (AHEAD && keep) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) sd[((lane >> 4) + 4 * r) * CH_LD + (lane & 15)] = c4[r];
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; r++) C[(int64_t)4 * r * np] = c4[r];
-            }
-        };
-        if (g_chol_scalar) {
-            for (int e = tid; e < m * 16 * m * 16; e += BA_T) {
-                const int r = e / (m * 16), c = e % (m * 16);
-                if (c > r) continue;
-                double v = 0;
-                for (int k = 0; k < 16; k++) v += P[r * CH_LD + k] * P[c * CH_LD + k];
-                A[(int64_t)((kb + 1) * 16 + r) * np + (kb + 1) * 16 + c] -= v;
-            }
-        } else if (AHEAD && m >= 1) {
-            if (wave == 0) {
-                update_tile(0, true);
-                CH_WAVE_SYNC();
-                factor_diag(kb + 1, true);
-            } else {
-                for (int t = wave; t < ntile; t += BA_W - 1) update_tile(t, false);
-            }
-            diag_done = true;
-        } else {
-            for (int t = wave; t < ntile; t += BA_W) update_tile(t, false);
+        for (int s4 = 0; s4 < 4; s4++) {
+            const double a = -P[(ii * 16 + (lane & 15)) * CH_LD + 4 * s4 + (lane >> 4)];
+            const double b = P[(jj * 16 + (lane & 15)) * CH_LD + 4 * s4 + (lane >> 4)];
+            c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c4, 0, 0, 0);
         }
-        __syncthreads();
-        CH_STAMP(4)
+        if (keep) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) sd[((lane >> 4) + 4 * r) * CH_LD + (lane & 15)] = c4[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; r++) C[(int64_t)4 * r * np] = c4[r];
+        }
+    };
+    auto update_scalar = [&](int kb, int m) { /* (debug) */
+        for (int e = tid; e < m * 16 * m * 16; e += BA_T) {
+            const int r = e / (m * 16), c = e % (m * 16);
+            if (c > r) continue;
+            double v = 0;
+            for (int k = 0; k < 16; k++) v += P[r * CH_LD + k] * P[c * CH_LD + k];
+            A[(int64_t)((kb + 1) * 16 + r) * np + (kb + 1) * 16 + c] -= v;
+        }
+    };
+    if (AHEAD) {
+        /* LOOK-AHEAD: step s runs the panel and the trailing update of column s and, beside the update, the factorisation
+           of diagonal tile s + 1 -- the first tile of the update IS that tile: the wavefront that updates it keeps it
+           (through `sd`: the accumulator layout is not the row-per-lane layout of the factorisation) and factorises it at
+           once, while the other seven wavefronts finish the update.  The sequential chain of the diagonal tile, half of a
+           solve, runs beside the only other phase that needs neither its result nor `sl`: Cholesky 5.3 -> 4.6 ms of a
+           100 x 5000 window's solve with ONE window in flight (its matrix resident in L2).  Step -1 is the factorisation
+           of tile 0 alone, so that the (several thousand instructions long) tile factorisation is inlined once.
+           With 256 windows in flight the look-ahead LOSES (9.95 against 8.75 ms per batch, also in this single-site
+           form, so it is not the instruction cache): the kept tile's read-modify-write comes from HBM and lands on
+           the chain; the batch instantiation takes the plain loop below. */
+        for (int s = -1; s < nb - 1; s++) {
+            const int m = s >= 0 ? elast[s] - s : 0; /* tile rows below the diagonal that reach column s */
+            if (m > 0) {
+                panel(s, m);
+                __syncthreads();
+            }
+            CH_STAMP(3)
+            const int ntile = m * (m + 1) / 2;
+            if (g_chol_scalar && m > 0) {
+                update_scalar(s, m);
+                __syncthreads();
+                if (wave == 0) factor_diag(s + 1, false);
+            } else if (wave == 0) {
+                if (m > 0) {
+                    update_tile(s, 0, true);
+                    CH_WAVE_SYNC();
+                }
+                factor_diag(s + 1, m > 0);
+            } else {
+                for (int t = wave; t < ntile; t += BA_W - 1) update_tile(s, t, false);
+            }
+            __syncthreads();
+            CH_STAMP(4)
+        }
+    } else {
+        for (int kb = 0; kb < nb; kb++) {
+            const int m = elast[kb] - kb; /* tile rows below the diagonal that reach column kb */
+            if (wave == 0) factor_diag(kb, false);
+            __syncthreads();
+            CH_STAMP(2)
+            panel(kb, m);
+            __syncthreads();
+            CH_STAMP(3)
+            if (g_chol_scalar) {
+                update_scalar(kb, m);
+            } else {
+                const int ntile = m * (m + 1) / 2;
+                for (int t = wave; t < ntile; t += BA_W) update_tile(kb, t, false);
+            }
+            __syncthreads();
+            CH_STAMP(4)
+        }
     }
     const bool ok = bad_flag[0] == 0.0;
     /* ---- forward substitution L y = g ---- */
