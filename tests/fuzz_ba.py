@@ -115,11 +115,14 @@ def run_batches(n_batches=2, seed=11, sample=3):
             if not ok and np.array_equal(g["outlier"], ref["outlier"]):
                 # a gauge-free window (one fixed camera) whose outliers are never switched off can be UNSTABLE as a problem
                 # (DESIGN.md section 2): measure its own sensitivity -- the oracle against itself with the input points scaled
-                # by (1 + 1e-13) -- and accept a deviation within a small multiple of it
-                wp = dict(w)
-                wp["points"] = w["points"] * (1 + 1e-13)
-                alt = orc.ba_solve(wp, rounds=rounds, robust=robust)
-                own = rel(alt["points"], ref["points"])
+                # by (1 +- 1e-13) -- and accept a deviation within a small multiple of it.  Both signs: a trial whose gain
+                # ratio sits at the acceptance threshold forks the trajectory for one of them only (seed 9301, batch 2,
+                # window 61: equal to 1e-10 through nine iterations, the tenth is accepted or rejected by rounding)
+                own = 0.0
+                for eps in (1e-13, -1e-13):
+                    wp = dict(w)
+                    wp["points"] = w["points"] * (1 + eps)
+                    own = max(own, rel(orc.ba_solve(wp, rounds=rounds, robust=robust)["points"], ref["points"]))
                 if own > 2e-7 and rel(g["points"], ref["points"]) < 50 * own:
                     print("   batch %d window %d: unstable problem (oracle vs itself at 1e-13: %.1e, device vs oracle: %.1e): accepted" % (
                         b, i, own, rel(g["points"], ref["points"])))
