@@ -55,6 +55,41 @@ def algorithmic_bytes_per_frame(level_sizes, n_kp):
 
 
 SINGLE_KERNEL_STAGES = ("fast", "quadtree", "blur", "describe", "match_knn", "match_resolve")
+# stage -> the kernel symbol(s) behind it (csrc/*.hip) and the source file the stage's PMC figures depend on
+STAGE_KERNEL = {"pyramid": "k_copy_level0 + k_resize x7", "fast": "k_fast_cells_wave", "quadtree": "k_quadtree",
+                "blur": "k_blur", "describe": "k_describe", "match_knn": "k_match_knn", "match_resolve": "k_match_init"}
+STAGE_SOURCE = {"pyramid": "orb_pyramid.hip", "blur": "orb_pyramid.hip", "fast": "orb_fast.hip", "quadtree": "orb_quadtree.hip",
+                "describe": "orb_describe.hip", "match_knn": "orb_match.hip", "match_resolve": "orb_match.hip",
+                "ba_iteration": "ba_api.hip"}
+
+
+def stage_source_hashes():
+    """sha256/16 of every kernel source file (+ orb_common.h, which they all include): stamped into
+    profiles/traffic.json by tools/collect_traffic.py when the PMC passes are collected"""
+    import hashlib
+    d = os.path.join(ROOT, "orbslam_in_practice_amd", "csrc")
+    common = open(os.path.join(d, "orb_common.h"), "rb").read()
+    return {f: hashlib.sha256(common + open(os.path.join(d, f), "rb").read()).hexdigest()[:16]
+            for f in sorted(set(STAGE_SOURCE.values()))}
+
+
+def load_traffic():
+    """profiles/traffic.json = PMC figures (HBM bytes, VALU instructions per launch) from separate rocprofv3 --pmc passes:
+    they are NOT measured in this run, so every stage whose kernel source has changed since the passes were collected is
+    dropped (-> null in the line) instead of going stale silently.  Returns (figures still valid, source tag)."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        tj = json.load(open(path))
+    except Exception:
+        return {}, None
+    stamped, now = tj.get("_src_sha16", {}), stage_source_hashes()
+    tj["_stale_valu"] = {}
+    for st, src in STAGE_SOURCE.items():
+        if stamped.get(src) != now[src]:
+            tj.pop(st, None)
+            if "valu_insts_" + st in tj:   # kept aside: still good enough to NAME the dominant kernel, never reported
+                tj["_stale_valu"][st] = tj.pop("valu_insts_" + st)
+    return tj, "profiles/traffic.json@%s (separate rocprofv3 --pmc passes; stages whose csrc changed since are null)" % tj.get("_collected", "?")
 
 
 def cpu_baseline(n_frames):
@@ -96,23 +131,106 @@ def cpu_baseline(n_frames):
     return one, allc
 
 
-def tracking_loop(n_frames):
-    """BASELINE configs[4] in the shape this repo can give it (orbslam_in_practice_amd/sequence.py): ONE stream through
-    extract -> SearchByProjection -> PoseOptimization per frame and a local BA per keyframe, the calls chained the way
-    Tracking / LocalMapping chain them, host-pointer API, Python glue included; ATE against the synthetic ground truth.
-    (The same loop on the CPU oracle -- identical matches and trajectory -- is tests/test_gpu_sequence.py's business.)"""
+def frontend_parity(frames, j, snap, chk, B, window):
+    """the oracle as the CHECKER of the timed region: frames `chk` of the last timed batch (batch j of the step = the
+    synthetic stream translated circularly by (7j, 13j) px) are extracted and matched by oracle/ and compared with the
+    slab rows and vnMatches12 rows the device left in HBM -- bit for bit (src/ORBextractor.cpp:1001-1065,
+    src/ORBmatcher.cpp:9-126 with the brute-force window)"""
+    from oracle import oracle as orc
+    o = orc.OrbOracle(NFEATURES, SCALE, NLEVELS, INI_TH, MIN_TH)
+    bounds = (0.0, float(W), 0.0, float(H))
+    feats = {i: o.extract(np.ascontiguousarray(np.roll(frames[i], (7 * j, 13 * j), axis=(0, 1)))) for i in chk}
+    res = {"frames": len(chk), "pairs": 0, "keypoints": 0, "keypoints_equal": True, "descriptors_equal": True,
+           "matches_equal": True, "matches": 0,
+           "checked": "frames %s of the LAST timed batch (slab rows + vnMatches12 rows left in HBM) vs oracle/, bit-exact" % chk}
+    for i in chk:
+        cnt, kps, desc, m12, nm = snap[i]
+        ok_, od = feats[i]
+        res["keypoints"] += cnt
+        same_n = cnt == len(ok_)
+        res["keypoints_equal"] &= bool(same_n and np.array_equal(kps[:cnt].reshape(-1).view(orc.KP_DTYPE), ok_))
+        res["descriptors_equal"] &= bool(same_n and np.array_equal(desc[:cnt], od))
+        if i + 1 in feats:     # pair (i, i+1)
+            on, om12, _ = orc.search_for_initialization(ok_, od, feats[i + 1][0], feats[i + 1][1], bounds, None, window, 0.9, True)
+            res["pairs"] += 1
+            res["matches"] += int(on)
+            res["matches_equal"] &= bool(same_n and nm == on and np.array_equal(m12[:cnt], om12))
+    res["ok"] = bool(res["keypoints_equal"] and res["descriptors_equal"] and res["matches_equal"] and res["pairs"] > 0)
+    return res
+
+
+def tracking_loop(n_frames, device=0, rank=0, world=1, barrier=None, max_over_ranks=None):
+    """BASELINE configs[4] in the shape this repo can give it (orbslam_in_practice_amd/sequence.py): ONE stream per GPU
+    through extract -> SearchByProjection -> PoseOptimization per frame and a local BA per keyframe, the calls chained
+    the way Tracking / LocalMapping chain them, host-pointer API, Python glue included; ATE against the synthetic
+    ground truth.  At N > 1 every rank runs its own stream (seed 5 + rank) between two barriers: value = world x frames
+    / the slowest rank's time.  (The same loop on the CPU oracle -- identical matches and trajectory -- is
+    tests/test_gpu_sequence.py's business.)"""
     from orbslam_in_practice_amd import sequence as sq
-    frames, gt, K, _ = sq.make_plane_sequence(5, n_frames)
-    be = sq.GpuBackend(NFEATURES, frames.shape[2], frames.shape[1])
+    frames, gt, K, _ = sq.make_plane_sequence(5 + rank, n_frames)
+    be = sq.GpuBackend(NFEATURES, frames.shape[2], frames.shape[1], device=device)
     sq.run_sequence(be, frames[:6], K, gt[0])  # warm-up
+    if barrier is not None:
+        barrier()
     t0 = time.perf_counter()
     r = sq.run_sequence(be, frames, K, gt[0])
     dt = time.perf_counter() - t0
+    if barrier is not None:
+        barrier()
+        dt = max_over_ranks(dt)
     be.close()
-    return {"value": round(n_frames / dt, 1), "unit": "frames/s", "ate_rmse_m": round(sq.ate_rmse(r["poses"], gt), 5),
+    return {"value": round(world * n_frames / dt, 1), "unit": "frames/s", "streams": world,
+            "ate_rmse_m": round(sq.ate_rmse(r["poses"], gt), 5),
             "local_ba_runs": int(r["ba_runs"]), "map_points": int(r["n_points"]), "mean_matches": round(float(r["n_matches"][1:].mean()), 1),
-            "workload": "%d synthetic frames %dx%d of a textured plane, %d features, keyframe every 4 frames, local BA over 5 "
-                        "keyframes; one stream, one frame at a time" % (n_frames, frames.shape[2], frames.shape[1], NFEATURES)}
+            "workload": "%d synthetic frames %dx%d of a textured plane per stream, %d features, keyframe every 4 frames, local BA "
+                        "over 5 keyframes; one stream per GPU, one frame at a time, Python glue in the loop"
+                        % (n_frames, frames.shape[2], frames.shape[1], NFEATURES)}
+
+
+def single_stream(n_frames):
+    """The reference's REAL call pattern, without Python in the loop: tests/cpp/tracking_main.cpp is a Tracking +
+    LocalMapping style loop in C++ on the drop-in classes with the reference's class names and signatures --
+    Frame(im, &extractor) (src/Frame.cpp:77), ORBmatcher(0.9, true).SearchByProjection(cur, last, th, true)
+    (src/Tracking.cpp:341-352), Optimizer::PoseOptimization(&cur) (:355), Optimizer::LocalBundleAdjustment(kf, &stop, &map)
+    per keyframe -- one frame at a time through host pointers.  Run as a child process on the same GPU (the bench's own
+    kernels are idle by then); built by __graft_entry__.build(), or here if the binary is missing."""
+    import subprocess
+    import tempfile
+    from orbslam_in_practice_amd import sequence as sq
+    exe = os.path.join(ROOT, "tests", "cpp", "build", "tracking_main")
+    try:
+        if not os.path.exists(exe):
+            import __graft_entry__ as ge
+            ge.build_cpp_loop()
+        td = tempfile.mkdtemp()
+        frames, gt, K, _ = sq.make_plane_sequence(5, n_frames)
+        frames.tofile(td + "/f.raw")
+        gt.astype(np.float64).tofile(td + "/gt.bin")
+        best = None
+        for _ in range(2):   # the first run pages the binary and the library in
+            p = subprocess.run([exe, str(frames.shape[2]), str(frames.shape[1]), str(n_frames), td + "/f.raw", td + "/gt.bin",
+                                *("%.17g" % v for v in K), td + "/out.bin"], capture_output=True, text=True, timeout=300)
+            if p.returncode != 0:
+                return {"error": "tracking_main exited with %d: %s" % (p.returncode, p.stderr[-200:])}
+            j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+            if best is None or j["secs"] < best["secs"]:
+                best = j
+        raw = open(td + "/out.bin", "rb").read()
+        rec = np.frombuffer(raw, np.dtype([("pose", "<f8", 7), ("nm", "<i4"), ("inl", "<i4")]), n_frames, 4)
+        j = best
+        track_s = j["secs"] - j["t_first"] - j["t_ba"]
+        return {"value": round((n_frames - 1) / track_s, 1), "unit": "frames/s",
+                "what": "tracking alone: Frame(im,&extractor) -> SearchByProjection -> PoseOptimization per frame, C++ on the drop-in classes",
+                "with_local_ba_frames_per_s": round((n_frames - 1) / (j["secs"] - j["t_first"]), 1),
+                "per_call_ms": {"Frame(im,&extractor)": round(j["ms_extract"], 4), "SearchByProjection": round(j["ms_sbp"], 4),
+                                "PoseOptimization": round(j["ms_po"], 4),
+                                "LocalBundleAdjustment": round(j["t_ba"] / max(j["ba_runs"], 1) * 1e3, 3)},
+                "local_ba_runs": j["ba_runs"], "map_points": j["map_points"],
+                "ate_rmse_m": round(sq.ate_rmse(rec["pose"].copy(), gt), 5), "mean_matches": round(float(rec["nm"][1:].mean()), 1),
+                "workload": "%d synthetic frames %dx%d, %d features, keyframe every 4 frames, local BA over the covisibility window"
+                            % (n_frames, frames.shape[2], frames.shape[1], NFEATURES)}
+    except Exception as e:   # a missing host compiler must not cost the driver its line
+        return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
 def ba_algorithmic_bytes(w, iterations, lin_solves):
@@ -156,6 +274,7 @@ def ba_bench(dev_index, rank, world, n_windows, nc, npt, reps, barrier, max_over
     res = opt.wait()
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
+    streamed = res   # outputs of the timed region's last batch: checked against the oracle below
     # one synchronous call, HIP events around the device work of every optimize() round (team == 0: the batch ran as
     # phase kernels, k_ba_ph_*; otherwise one k_ba_iteration launch per round): the roofline of the BA kernels
     opt.set_profiling(True)
@@ -167,15 +286,12 @@ def ba_bench(dev_index, rank, world, n_windows, nc, npt, reps, barrier, max_over
     by_uniq = [ba_algorithmic_bytes(uniq[i], res[i]["iterations"], res[i]["lin_solves"]) for i in range(n_uniq)]
     total_bytes = sum(by_uniq[i % n_uniq] for i in range(n_windows))
     a = total_bytes / max(launches, 1) / (iter_ms * 1e-3) / 1e9 if iter_ms > 0 else 0.0
+    tj, traffic_src = load_traffic()
     traffic = None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        if "ba_iteration" in tj:
-            traffic = int(tj["ba_iteration"] * n_windows / float(tj.get("_ba_batch", n_windows)))
-    except Exception:
-        pass
+    if "ba_iteration" in tj:
+        traffic = int(tj["ba_iteration"] * n_windows / float(tj.get("_ba_batch", n_windows)))
     roof = {"bound": "hbm", "kernel": "k_ba_ph_* (the phase kernels of one optimize() round)" if team == 0 else "k_ba_iteration", "achieved": round(a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(a / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "frac": round(a / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src if traffic is not None else None,
             "algorithmic_bytes_per_launch": int(total_bytes / max(launches, 1)), "windows_per_launch": n_windows,
             "launches": launches, "avg_launch_ms": round(iter_ms, 4), "workgroups_per_window": team,
             "lin_solves_per_window": round(float(np.mean([r["lin_solves"] for r in res])), 2)}
@@ -199,16 +315,35 @@ def ba_bench(dev_index, rank, world, n_windows, nc, npt, reps, barrier, max_over
            "single_window_ms": round(single_ms, 3), "single_window_windows_per_s": round(1e3 / single_ms, 2),
            "single_window": {"workgroups_per_window": s_team, "avg_iteration_launch_ms": round(s_ms, 4), "launches": s_launches},
            "chi2_ratio": round(float(np.mean([r["chi2_final"] / r["chi2_initial"] for r in res])), 5)}
-    if with_cpu:
+    if rank == 0:
         # the CPU oracle (dense Cholesky on the Schur complement, g2o semantics) on a bounded sample of the same windows
+        # (N > 1: two windows, as the checker only -- the other ranks wait at the final barrier meanwhile)
         from oracle import oracle as orc
-        ncpu = min(8, n_uniq)
+        ncpu = min(8 if with_cpu else 2, n_uniq)
         t3 = time.perf_counter()
-        for w in uniq[:ncpu]:
-            orc.ba_solve(w, rounds=(5, 10))
+        refs = [orc.ba_solve(w, rounds=(5, 10)) for w in uniq[:ncpu]]
         cpu_dt = (time.perf_counter() - t3) / ncpu
-        out["cpu_baseline"] = {"value": round(1.0 / cpu_dt, 3), "unit": "windows/s", "cores": 1, "kind": "port",
-                               "sample": "%d of the same windows through oracle/ba_oracle.cpp, %.1f s" % (ncpu, cpu_dt * ncpu)}
+        if with_cpu:
+            out["cpu_baseline"] = {"value": round(1.0 / cpu_dt, 3), "unit": "windows/s", "cores": 1, "kind": "port",
+                                   "sample": "%d of the same windows through oracle/ba_oracle.cpp, %.1f s" % (ncpu, cpu_dt * ncpu)}
+        # ... and the SAME solves are the checker of the timed stream: `streamed` holds the results of the last batch of
+        # the timed region (ba_submit_batch / ba_wait, phase kernels), window i of it = uniq[i]
+        rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+        par = {"windows": ncpu, "launch_shape": "phase kernels" if team == 0 else "team of %d" % team,
+               "max_rel_points": 0.0, "max_rel_trans": 0.0, "max_abs_quat": 0.0, "max_rel_chi2": 0.0,
+               "outliers_equal": True, "iterations_equal": True, "tolerance": 1e-5,
+               "checked": "windows 0..%d of the LAST timed batch vs oracle.ba_solve" % (ncpu - 1)}
+        for i, r in enumerate(refs):
+            g = streamed[i]
+            par["max_rel_points"] = max(par["max_rel_points"], rel(g["points"], r["points"]))
+            par["max_rel_trans"] = max(par["max_rel_trans"], rel(g["poses"][:, 4:], r["poses"][:, 4:]))
+            par["max_abs_quat"] = max(par["max_abs_quat"], float(np.abs(g["poses"][:, :4] - r["poses"][:, :4]).max()))
+            par["max_rel_chi2"] = max(par["max_rel_chi2"], abs(g["chi2_final"] - r["chi2_final"]) / r["chi2_final"])
+            par["outliers_equal"] &= bool(np.array_equal(g["outlier"], r["outlier"]))
+            par["iterations_equal"] &= bool(g["iterations"] == r["iterations"])
+        par["ok"] = bool(par["outliers_equal"] and par["iterations_equal"] and
+                         max(par["max_rel_points"], par["max_rel_trans"], par["max_abs_quat"], par["max_rel_chi2"]) < 1e-5)
+        out["parity"] = par
     return out
 
 
@@ -229,19 +364,26 @@ def main():
     ap.add_argument("--ba-windows", type=int, default=256, help="local-BA windows per GPU per batch (0 = skip)")
     ap.add_argument("--ba-size", default="100x5000", help="keyframes x points of a window (configs[2] = 50x2000)")
     ap.add_argument("--ba-reps", type=int, default=24, help="batches in the timed BA stream")
-    ap.add_argument("--sequence-frames", type=int, default=40, help="frames of the one-stream tracking loop (rank 0, N=1; 0 = skip)")
+    ap.add_argument("--sequence-frames", type=int, default=40, help="frames of the one-stream-per-GPU tracking loop (0 = skip)")
     args = ap.parse_args()
     W, H = (int(v) for v in args.size.lower().split("x"))
     NFEATURES = args.nfeatures
-
-    import torch
-    import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    # The C++ one-stream loop is a CHILD process on the same GPU: it runs first, before this process creates its own HIP
+    # queues (two processes' queues on one device are time-sliced by the hardware scheduler: 3.5 ms per frame instead of
+    # 1.2 when the loop ran after the bench's streams existed)
+    single = None
+    if args.sequence_frames > 0 and rank == 0 and world == 1:
+        single = single_stream(max(args.sequence_frames, 80))
+
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product has no CPU fallback)")
     # REHEARSAL ONLY (one-GPU box): BENCH_REHEARSE=1 puts every rank on cuda:0 and swaps RCCL for gloo, to
@@ -367,6 +509,13 @@ def main():
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
 
+    # outputs of the timed region's LAST batch (batch S-1 of the step, in the slab it went to): a few frames at the start
+    # of the batch and on both sides of the lane boundary are copied out now and checked against the oracle below
+    last_slab, last_j = slabs[(batch_no[0] - 1) & 1], S - 1
+    chk = sorted(set(i for i in list(range(3)) + list(range(Bh - 1, Bh + 2)) if i < B))
+    snap = {i: (int(last_slab.cnt[i]), last_slab.kps[i].cpu().numpy(), last_slab.desc[i].cpu().numpy(),
+                last_slab.m12[i].cpu().numpy(), int(last_slab.nm[i])) for i in chk} if rank == 0 else {}
+
     # per-stage durations: a SEPARATE pass after the timed region, HIP events on the launch streams between the stages
     oa._lib.check(L.orb_set_profiling(ext._h, 1))
     oa._lib.check(L.orb_matcher_set_profiling(matcher._m, 1))
@@ -391,16 +540,14 @@ def main():
         local_ba = ba_bench(local_rank, rank, world, args.ba_windows, nc, npt, max(2, args.ba_reps), barrier, max_over_ranks,
                             with_cpu=(rank == 0 and world == 1))
 
+    tl = None
+    if args.sequence_frames > 0:
+        tl = tracking_loop(args.sequence_frames, local_rank, rank, world, barrier, max_over_ranks)
+    rc = 0
     if rank == 0:
         fps = world * B * S * args.steps / elapsed
         ab = algorithmic_bytes_per_frame(ext.level_sizes(W, H), n_kp)
-        tj = {}
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-            except Exception:
-                tj = {}
+        tj, traffic_src = load_traffic()
         # The dominant KERNEL.  The two launch lanes keep the GPU's vector ALUs ~95 % busy (profiles/r02_pmc_sq_*.json), so
         # the kernel that bounds the pipeline is the one that issues the most VALU instructions per batch (PMC
         # SQ_INSTS_VALU, profiles/traffic.json), not the one whose in-flight HIP-event interval happens to be longest
@@ -408,7 +555,8 @@ def main():
         # while occupying a few percent of the machine.  Without the PMC file: the longest single-launch stage.
         # ("pyramid" is several launches -- level-0 copy + resizes -- and is listed under roofline_stages only)
         timed = {k: v for k, v in stage_ms.items() if ab.get(k, 0) > 0 and k in SINGLE_KERNEL_STAGES}
-        by_valu = {k: tj["valu_insts_" + k] for k in timed if "valu_insts_" + k in tj}
+        by_valu = {k: tj.get("valu_insts_" + k, tj.get("_stale_valu", {}).get(k)) for k in timed}
+        by_valu = {k: v for k, v in by_valu.items() if v is not None}
         dom = max(by_valu, key=by_valu.get) if by_valu else max(timed, key=timed.get)
 
         def stage_roofline(k):
@@ -416,13 +564,14 @@ def main():
             # per-frame traffic is batch independent
             a = ab[k] * Bh / (stage_ms[k] * 1e-3) / 1e9
             t = int(tj[k] * Bh / float(tj.get("_batch", Bh))) if k in tj else None
-            r = {"bound": "hbm", "kernel": k, "achieved": round(a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                 "frac": round(a / HBM_PEAK_GBS, 5), "traffic": t, "algorithmic_bytes_per_launch": int(ab[k] * Bh),
+            r = {"bound": "hbm", "kernel": STAGE_KERNEL[k], "stage": k, "achieved": round(a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(a / HBM_PEAK_GBS, 5), "traffic": t, "traffic_source": traffic_src if t is not None else None,
+                 "algorithmic_bytes_per_launch": int(ab[k] * Bh),
                  "frames_per_launch": Bh, "avg_launch_ms": round(stage_ms[k], 4)}
             vk = "valu_insts_" + k  # SQ_INSTS_VALU per launch (PMC pass, profiles/traffic.json): issue-rate view of a VALU-bound kernel
             if vk in tj:
                 ginst = tj[vk] * Bh / float(tj.get("_batch", Bh)) / 1e9
-                r["valu"] = {"insts_per_launch": int(ginst * 1e9), "achieved_ginst_s": round(ginst / (stage_ms[k] * 1e-3), 1),
+                r["valu"] = {"source": traffic_src, "insts_per_launch": int(ginst * 1e9), "achieved_ginst_s": round(ginst / (stage_ms[k] * 1e-3), 1),
                              "peak_ginst_s": VALU_PEAK_GINST, "frac": round(ginst / (stage_ms[k] * 1e-3) / VALU_PEAK_GINST, 4)}
             return r
         pipe_bytes = sum(ab.values()) * world * B * S * args.steps
@@ -453,14 +602,22 @@ def main():
         }
         if world == 1 and args.cpu_frames > 0:
             out["cpu_baseline"], out["cpu_baseline_all_cores"] = cpu_baseline(args.cpu_frames)
+        out["parity"] = frontend_parity(frames, last_j, snap, chk, B, args.window)
         if local_ba is not None:
             out["local_ba"] = local_ba
-        if world == 1 and args.sequence_frames > 0:
-            out["tracking_loop"] = tracking_loop(args.sequence_frames)
+        if tl is not None:
+            out["tracking_loop"] = tl
+        if single is not None:
+            out["single_stream"] = single
         print(json.dumps(out), flush=True)
+        bad = [k for k, blk in (("parity", out["parity"]), ("local_ba.parity", (local_ba or {}).get("parity"))) if blk and not blk["ok"]]
+        if bad:
+            sys.stderr.write("bench.py: outputs of the timed region differ from the oracle: %s\n" % ", ".join(bad))
+            rc = 3
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -29,7 +29,8 @@ enum {
     ORB_E_ASPECT = -5,    /* image so tall that the reference's quadtree root count rounds to 0 (the
                              reference divides by zero there, src/ORBextractor.cpp:493-495)           */
     ORB_E_STOPPED = -6,   /* ba_solve: *stop became true before the first iteration                    */
-    ORB_E_BUSY = -7       /* ba_submit_batch: two batches already in flight (call ba_wait first)       */
+    ORB_E_RESERVED_7 = -7, /* retired (was ORB_E_SINGULAR in round 1): never returned, never reused        */
+    ORB_E_BUSY = -8       /* ba_submit_batch: two batches already in flight (call ba_wait first)       */
 };
 
 const char *orb_last_error(void);

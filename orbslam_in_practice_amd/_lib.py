@@ -17,9 +17,9 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4
 assert KP_DTYPE.itemsize == 28
 
 ORB_OK, ORB_E_INVALID, ORB_E_CAPACITY, ORB_E_NO_DEVICE, ORB_E_HIP, ORB_E_ASPECT, ORB_E_STOPPED, ORB_E_BUSY = \
-    0, -1, -2, -3, -4, -5, -6, -7
+    0, -1, -2, -3, -4, -5, -6, -8      # -7 is retired (round 1's ORB_E_SINGULAR) and never reused
 _ERR_NAMES = {-1: "ORB_E_INVALID", -2: "ORB_E_CAPACITY", -3: "ORB_E_NO_DEVICE", -4: "ORB_E_HIP",
-              -5: "ORB_E_ASPECT", -6: "ORB_E_STOPPED", -7: "ORB_E_BUSY"}
+              -5: "ORB_E_ASPECT", -6: "ORB_E_STOPPED", -7: "ORB_E_RESERVED_7", -8: "ORB_E_BUSY"}
 
 
 class OrbError(RuntimeError):

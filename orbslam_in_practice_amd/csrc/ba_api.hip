@@ -40,6 +40,7 @@
 
 #include "../../include/orbslam_amd.h"
 #include "orb_common.h" /* PerDeviceLdsLimit */
+void orb_trace_exit_late(); /* orb_api.hip: exit-handler marker for tools/exit_hang_probe.sh */
 
 #define BA_T 512
 #define BA_W (BA_T / 64)
@@ -3040,6 +3041,7 @@ extern "C" int ba_create(int max_cams, int max_points, int max_obs, int max_batc
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return ORB_E_NO_DEVICE;
     BCHK(hipSetDevice(device_id));
+    orb_trace_exit_late();
     BASolver *s = new BASolver();
     s->device = device_id;
     s->max_cams = max_cams;
@@ -3077,8 +3079,22 @@ extern "C" int ba_create(int max_cams, int max_points, int max_obs, int max_batc
     return ORB_OK;
 }
 
+/* ORBSLAM_AMD_TRACE_EXIT=1: markers on stderr around the teardown (tools/exit_hang_probe.sh) */
+static bool ba_trace_exit() {
+    static const bool on = getenv("ORBSLAM_AMD_TRACE_EXIT") != nullptr;
+    return on;
+}
+namespace {
+struct BAExitMarker {
+    ~BAExitMarker() {
+        if (ba_trace_exit()) fprintf(stderr, "[liborbslam_amd] static destructor of ba_api (exit handlers are running)\n");
+    }
+} g_ba_exit_marker;
+}
+
 extern "C" void ba_destroy(BASolver *s) {
     if (!s) return;
+    if (ba_trace_exit()) fprintf(stderr, "[liborbslam_amd] ba_destroy: begin\n");
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->copy_in) (void)hipStreamSynchronize(s->copy_in);
@@ -3106,6 +3122,7 @@ extern "C" void ba_destroy(BASolver *s) {
     if (s->copy_in) (void)hipStreamDestroy(s->copy_in);
     if (s->copy_out) (void)hipStreamDestroy(s->copy_out);
     delete s;
+    if (ba_trace_exit()) fprintf(stderr, "[liborbslam_amd] ba_destroy: end\n");
 }
 
 extern "C" int ba_set_profiling(BASolver *s, int enable) {
@@ -3177,7 +3194,8 @@ static int ba_choose_team(BASolver *s, int nwin, int maxE) {
 static int ba_stage(BASolver *s, BAJob &J, const BAProblem *probs, BAResult *res, int nwin) {
     const BAProblem &P0 = probs[0];
     for (int i = 0; i < nwin; i++) {
-        if (probs[i].n_rounds != P0.n_rounds || memcmp(probs[i].rounds, P0.rounds, sizeof(P0.rounds)) ||
+        if (probs[i].n_rounds != P0.n_rounds || P0.n_rounds < 0 || P0.n_rounds > (int)(sizeof(P0.rounds) / sizeof(P0.rounds[0])) ||
+            memcmp(probs[i].rounds, P0.rounds, (size_t)P0.n_rounds * sizeof(P0.rounds[0])) ||   /* entries past n_rounds are the caller's to leave unset */
             probs[i].drop_robust_after != P0.drop_robust_after) {
             b_err = "ba_solve_batch: all windows of a batch must share one iteration schedule";
             return ORB_E_INVALID;
@@ -3596,10 +3614,10 @@ extern "C" int ba_submit_batch(BASolver *s, const BAProblem *probs, BAResult *re
 extern "C" int ba_wait(BASolver *s) {
     if (!s) return ORB_E_INVALID;
     if (s->in_flight <= 0) return ORB_OK;
-    BCHK(hipSetDevice(s->device));
-    BAJob &J = s->job[s->oldest_slot];
-    s->oldest_slot ^= 1;
+    BAJob &J = s->job[s->oldest_slot]; /* the oldest batch is retired whatever happens below: callers that mirror */
+    s->oldest_slot ^= 1;               /* the queue (optimizer.py) pop their entry before looking at the status   */
     s->in_flight--;
+    BCHK(hipSetDevice(s->device));
     return ba_finish(s, J);
 }
 

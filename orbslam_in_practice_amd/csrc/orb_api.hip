@@ -36,6 +36,21 @@ static void set_err(const char *what, hipError_t e, const char *file, int line) 
 extern "C" const char *orb_last_error(void) { return g_err.c_str(); }
 void orb_set_last_error(const char *msg) { g_err = msg ? msg : ""; }
 
+/* ORBSLAM_AMD_TRACE_EXIT=1 (tools/exit_hang_probe.sh): stderr markers that bracket this library's share of the exit
+ * handlers.  orb_exit_marker_after_modules is registered from a priority constructor, i.e. BEFORE the hipcc module
+ * constructors register their __hip_module_dtor, so it runs AFTER the library's code objects were unregistered;
+ * orb_trace_exit_late() is called by ba_create and registers a handler that runs BEFORE them. */
+static void orb_exit_marker_after_modules() { fprintf(stderr, "[liborbslam_amd] exit: code objects unregistered (all __hip_module_dtor done)\n"); }
+static void orb_exit_marker_before_modules() { fprintf(stderr, "[liborbslam_amd] exit: handler registered at the first create() runs now\n"); }
+__attribute__((constructor(101))) static void orb_register_exit_markers() {
+    if (getenv("ORBSLAM_AMD_TRACE_EXIT")) atexit(orb_exit_marker_after_modules);
+}
+void orb_trace_exit_late() {
+    static bool done = false;
+    if (!done && getenv("ORBSLAM_AMD_TRACE_EXIT")) atexit(orb_exit_marker_before_modules);
+    done = true;
+}
+
 extern "C" int orb_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -21,6 +21,7 @@ class Optimizer:
     def __init__(self, max_cams=128, max_points=8192, max_obs=65536, max_batch=1, device=0):
         self._L = _lib.lib()
         self._s = C.c_void_p()
+        self._jobs = []   # submitted, not yet waited-for batches, oldest first: mirrors the C side's queue slot by slot
         check(self._L.ba_create(max_cams, max_points, max_obs, max_batch, device, C.byref(self._s)))
 
     def close(self):
@@ -84,6 +85,9 @@ class Optimizer:
         return job["outs"]
 
     def solve_batch(self, windows, rounds, robust=True, chi2_threshold=CHI2_2D, drop_robust_after=0, stop=None):
+        if self._jobs:
+            # ba_solve_batch would drain the submitted batches inside C and leave their result buffers unclaimed here
+            raise RuntimeError("solve_batch with %d submitted batch(es) in flight: call wait() first" % len(self._jobs))
         job = self._prepare(windows, rounds, robust, chi2_threshold, drop_robust_after, stop)
         check(self._L.ba_solve_batch(self._s, job["Ps"], job["Rs"], job["n"]))
         return self._collect(job)
@@ -92,13 +96,17 @@ class Optimizer:
         """ba_submit_batch: stage + enqueue, returns at once (two batches may be in flight); pair with wait()"""
         job = self._prepare(windows, rounds, robust, chi2_threshold, drop_robust_after, None)
         check(self._L.ba_submit_batch(self._s, job["Ps"], job["Rs"], job["n"]))
-        self._jobs = getattr(self, "_jobs", [])
         self._jobs.append(job)   # keeps every buffer the C side points into alive until wait()
 
     def wait(self):
-        """ba_wait: results of the OLDEST submitted batch"""
-        check(self._L.ba_wait(self._s))
-        return self._collect(self._jobs.pop(0))
+        """ba_wait: results of the OLDEST submitted batch.  The C side retires that batch whether or not it
+        succeeded, so the job leaves this queue before the status is looked at: the two queues stay aligned."""
+        if not self._jobs:
+            raise RuntimeError("wait() without a submitted batch")
+        rc = self._L.ba_wait(self._s)
+        job = self._jobs.pop(0)
+        check(rc)
+        return self._collect(job)
 
     def set_profiling(self, on=True):
         check(self._L.ba_set_profiling(self._s, 1 if on else 0))

@@ -101,12 +101,12 @@ class GpuBackend:
     """the product: HIP kernels through the C-ABI (fails loudly when liborbslam_amd.so is missing)"""
     name = "gpu"
 
-    def __init__(self, nfeatures, w, h):
+    def __init__(self, nfeatures, w, h, device=0):
         import orbslam_in_practice_amd as oa
         self.oa = oa
-        self.ext = oa.ORBextractor(nfeatures, 1.2, 8, 20, 7, max_w=w, max_h=h, max_batch=1)
-        self.matcher = oa.ORBmatcher(0.9, True, max_keypoints=self.ext.cap, max_pairs=1)
-        self.opt = oa.Optimizer(max_cams=16, max_points=8192, max_obs=65536, max_batch=1)
+        self.ext = oa.ORBextractor(nfeatures, 1.2, 8, 20, 7, max_w=w, max_h=h, max_batch=1, device=device)
+        self.matcher = oa.ORBmatcher(0.9, True, max_keypoints=self.ext.cap, max_pairs=1, device=device)
+        self.opt = oa.Optimizer(max_cams=16, max_points=8192, max_obs=65536, max_batch=1, device=device)
         self.bounds = (0.0, float(w), 0.0, float(h))
         self.scale_factors = np.asarray(self.ext.GetScaleFactors(), np.float32)
         self.inv_sigma2 = np.asarray(self.ext.GetInverseScaleSigmaSquares(), np.float64)

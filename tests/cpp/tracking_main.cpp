@@ -241,5 +241,9 @@ int main(int argc, char **argv) {
                 n, secs, n / secs, t_first, ba_runs, t_ba, (n - 1) / (secs - t_first - t_ba), npts);
     std::printf("  per frame: Frame(im, &extractor) %.3f ms, SearchByProjection %.3f ms, PoseOptimization %.3f ms\n", t_ext / (n - 1) * 1e3,
                 t_sbp / (n - 1) * 1e3, t_po / (n - 1) * 1e3);
+    /* machine-readable summary for bench.py's single_stream block */
+    std::printf("{\"frames\": %d, \"secs\": %.6f, \"t_first\": %.6f, \"t_ba\": %.6f, \"ba_runs\": %d, \"map_points\": %d, "
+                "\"ms_extract\": %.5f, \"ms_sbp\": %.5f, \"ms_po\": %.5f}\n",
+                n, secs, t_first, t_ba, ba_runs, npts, t_ext / (n - 1) * 1e3, t_sbp / (n - 1) * 1e3, t_po / (n - 1) * 1e3);
     return 0;
 }

@@ -61,6 +61,7 @@ def _worker(rank, world, port, q):
     s_c[:FPR] = torch.from_numpy(cnt)
     ex = shard.HaloExchange(world, FPR)
     ex(s_k, s_d, s_c)
+    assert ex.collectives == 1          # a single fused all-gather per batch (packed [kps | desc | cnt] record)
     K = s_k.numpy().reshape(rows, CAP * 28).view(orc.KP_DTYPE).reshape(rows, CAP)
     a, b = shard.halo_pairs(rank, world, FPR)
     res = _match(K, s_d.numpy(), s_c.numpy(), a, b)

@@ -39,6 +39,7 @@ def _device_run(frames, rank, world, exchange):
                                  d_cnt.data_ptr(), sp)
         if exchange is not None:
             exchange(d_kps, d_desc, d_cnt)
+            assert exchange.collectives == 1     # the packed slab: ONE all-gather per batch
         m.match_batch_device(d_kps.data_ptr(), d_desc.data_ptr(), d_cnt.data_ptr(), cap, pa.data_ptr(), pb.data_ptr(), B,
                              (0.0, float(W), 0.0, float(H)), -1, d_m12.data_ptr(), d_nm.data_ptr(), sp)
     torch.cuda.synchronize()

@@ -16,7 +16,14 @@ import collections
 import csv
 import glob
 import json
+import os
+import subprocess
 import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import stage_source_hashes  # noqa: E402  (what bench.py compares the stamp with)
 
 STAGE = {"k_ba_iteration": "ba_iteration", "k_pyramid": "pyramid", "k_copy_level0": "pyramid", "k_resize": "pyramid", "k_fast_cells": "fast", "k_fast_cells_wave": "fast", "k_quadtree": "quadtree",
          "k_blur": "blur", "k_describe": "describe", "k_match_knn": "match_knn", "k_match_init": "match_resolve"}
@@ -73,6 +80,13 @@ def main():
     if calls["ba_iteration"] and PHASE["FETCH_SIZE"]:  # bytes per optimize() round and phase kernel
         res["_ba_phase_bytes"] = {k: int((PHASE["FETCH_SIZE"][k] * 2.0 + PHASE["WRITE_SIZE"].get(k, 0.0)) * 1024.0 / calls["ba_iteration"])
                                   for k in sorted(PHASE["FETCH_SIZE"])}
+    # stamp: bench.py nulls every stage whose kernel source no longer hashes to what the PMC passes ran
+    res["_src_sha16"] = stage_source_hashes()
+    try:
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except Exception:
+        head = ""
+    res["_collected"] = "%s%s" % (time.strftime("%Y-%m-%d"), (" after " + head) if head else "")
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res))
 
