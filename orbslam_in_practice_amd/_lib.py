@@ -83,6 +83,16 @@ def lib():
             "orbslam_in_practice_amd: %s is missing -- build it with `make -C %s` (or "
             "__graft_entry__.build()).  This package has no CPU fallback." % (LIB_PATH, CSRC))
     L = C.CDLL(LIB_PATH)
+    if os.environ.get("ROCP_TOOL_LIBRARIES"):
+        # Running under rocprofv3.  A --pmc pass post-processes every dispatch on a worker thread of the profiler; a
+        # process that leaves right after a burst of launches (a BA batch = ~800 dispatches in 60 ms) meets that
+        # thread inside exit(): the tool finalises, and the worker then crashes or deadlocks in the tool's own
+        # containers -- AFTER every handle of this library was destroyed and its code objects were unregistered
+        # (gpurun_out evidence summarised in profiles/r03_profiler_exit_hang.md: 12 of 12 undrained exits failed, 6 of
+        # 6 drained ones were clean, on one box).  Give the worker two seconds before the interpreter goes away.
+        import atexit
+        import time
+        atexit.register(time.sleep, 2.0)
     vp, i32, f32, i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
     L.orb_last_error.restype = C.c_char_p
     L.orb_device_count.restype = C.c_int

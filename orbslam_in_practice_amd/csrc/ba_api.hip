@@ -80,6 +80,7 @@ struct BAWin {
     /* doubles */
     int64_t poses, poses_t, pts, pts_t, obs, info, err, err_t, W, tv, Hpp, bp, Hll, bl, Dinv, S, g, Minv, x, xl, st;
     int64_t A, Linv; /* dense reduced system (np x np) and inverse diagonal blocks of its Cholesky factor */
+    int64_t fplan;   /* doubles offset (scratch), read as ints: fill plan of the band Cholesky (k_ba_ph_fillplan); -1: none */
     int64_t Uf, tu;  /* per point: the upper-triangular U with Dinv = U U^T (6 doubles) and u = U^T bl (phase-kernel Schur pass) */
     int64_t Rc;      /* rotation matrices of the cameras (9 doubles each), written by the camera pass of the phase-kernel path */
     int64_t S2, g2;  /* second accumulator of the Schur products and of g (phase-kernel path: the window's chunks are split
@@ -770,6 +771,380 @@ __device__ __noinline__ bool ba_chol_solve(const BAWin &w, double *D, const int3
     for (int i = tid; i < n; i += BA_T) D[w.x + i] = ok ? z[i] : 0.0;
     __syncthreads();
     CH_STAMP(6)
+    return ok;
+}
+
+/* ------------------------------------------------------------------------------------------------------------
+ * BAND Cholesky with an LDS-resident sliding window (round 3): the same factorisation as ba_chol_solve -- 16 x 16 tiles,
+ * the diagonal tile and its inverse by one wavefront in registers, panel and trailing update on v_mfma_f64_16x16x4 --
+ * with NO global-memory round trip on its sequential chain.
+ *
+ * Local-BA windows are chain-like: the envelope of S is a band (100 keyframes x 5000 points: 38 tile rows, at most
+ * M = 4 tile rows below a diagonal tile reach its column), and a step of the factorisation is tiny (<= M panel tiles,
+ * <= M (M + 1) / 2 update tiles).  What a step cost in ba_chol_solve (12 us, 38 of them per solve) was latency: the
+ * diagonal tile, the panel and the trailing tiles each came from and went back to global memory -- HBM, with a few
+ * hundred windows in flight -- and so did the rows of the backward substitution.  Here:
+ *
+ *   - the tiles that are still being updated live in LDS: tile (i, j), d = i - j, sits in ring d at position
+ *     j mod (M + 2 - d).  At step s the live tiles of diagonal d are the columns s .. elast[s + 1] - d, a contiguous
+ *     range no longer than the ring, so the modular index never collides; all rings together hold (M + 1)(M + 4) / 2
+ *     tiles (M = 4: 20 tiles = 43 KB);
+ *   - a tile row ENTERS the window one step before its first column is eliminated, straight from the block-sparse S
+ *     (+ S2 of the two-part Schur pass): the dense np x np matrix is never assembled in memory (zero fill + scatter +
+ *     first read of the envelope were a sixth of the batch's HBM traffic).  Its loads are a chain of two round trips
+ *     (fill plan entry -> S value) and are taken OFF the factorisation's chain by software pipelining across the steps:
+ *     step s issues the plan loads of the rows that enter at step s + 2 and the S loads of those that enter at s + 1,
+ *     and writes the values that arrived for the rows entering now -- the step barriers inside the loop are raw
+ *     s_barrier with an LDS-only wait (chb_barrier), so loads stay in flight across them.  The FILL PLAN (per
+ *     lower-triangle entry of S inside the envelope: source index, needs-S2 flag, LDS offset of its destination) is a
+ *     function of the window's pattern alone: built once per batch by k_ba_ph_fillplan, read by every trial;
+ *   - LOOK-AHEAD: the wavefront that updates tile (s + 1, s + 1) factorises it at once, beside the rest of the
+ *     trailing update -- with the tiles in LDS the kept tile no longer drags an HBM read-modify-write onto the chain
+ *     (why the look-ahead lost on the batch path in round 2);
+ *   - the forward substitution rides along (y_s = L_ss^-1 z_s during the panel, z_i -= L_is y_s during the update);
+ *   - finished panel tiles and inverse diagonal tiles go to memory once, for the backward substitution (x_i = L_ii^-T
+ *     z_i, then z_j -= L_ij^T x_i over the columns j of row i's envelope: contiguous in memory, one lane per column):
+ *     row i belongs to wavefront i mod NW, which holds it in registers and reloads them with its next row right after
+ *     use -- every row is requested NW steps before it is needed.
+ *
+ * NT threads per window (256: two windows share a CU -- one's chain overlaps the other's products; 512 for batches
+ * that cannot fill the device twice).  Same arithmetic per entry as ba_chol_solve up to the order of the MFMA
+ * accumulations (none changed), so results agree to rounding; the oracle tests hold both. */
+#define CHB_TILE (16 * CH_LD)
+#define CHB_MAX_M 8     /* widest band (tile rows below a diagonal tile) the band kernel takes */
+#define CHB_MAX_NB 1024 /* most tile rows (k_ba_ph_fillplan counts per tile row in LDS) */
+__host__ __device__ __forceinline__ int chb_ring(int M, int d) { return M + 2 - d; }
+__host__ __device__ __forceinline__ int chb_base(int M, int d) { return d * (M + 2) - d * (d - 1) / 2; }
+__host__ __device__ __forceinline__ int chb_slots(int M) { return chb_base(M, M + 1); }
+__host__ __device__ __forceinline__ int chb_ent0(int nb) { return (nb + 2) & ~1; } /* first entry of a fill plan, in ints (8-byte aligned) */
+/* doubles of dynamic LDS: tile rings, inverse of the current diagonal tile, z, and (as ints) efirst / elast / plan starts */
+__host__ __device__ __forceinline__ size_t chb_lds_doubles(int M, int np) {
+    return (size_t)chb_slots(M) * CHB_TILE + CHB_TILE + np + 16 + (3 * (size_t)(np / 16 + 4) + 1) / 2;
+}
+/* workgroup barrier that waits for this wave's LDS operations only: global loads issued before it stay in flight */
+__device__ __forceinline__ void chb_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+/* the fill plan of a window (once per batch): plan ints = [ starts: nb + 1 | entries: 2 per lower-triangle scalar of S ]
+   entry = { source index into S (bit 31: add S2), LDS double offset of the destination inside the tile rings } */
+__global__ __launch_bounds__(256) void k_ba_ph_fillplan(BABufs bufs) {
+    __shared__ int cnt[CHB_MAX_NB + 1];
+    const BAWin w = bufs.wins[blockIdx.x];
+    const int32_t *I = bufs.I;
+    if (w.fplan < 0) return;
+    int32_t *plan = (int32_t *)(bufs.D + w.fplan);
+    const int n = w.Ncf * 6, np = (n + 15) & ~15, nb = np >> 4, M = w.ch_pm >> 4;
+    const int32_t *efirst = I + w.ch_first;
+    for (int i = threadIdx.x; i <= nb; i += 256) cnt[i] = 0;
+    __syncthreads();
+    for (int pass = 0; pass < 2; pass++) {
+        for (int it = threadIdx.x; it < w.nnzb * 36; it += 256) {
+            const int bk = it / 36, e = it - bk * 36;
+            const int c = I[w.blk_rowid + bk], j = I[w.blk_col + bk];
+            if (j > c) continue;
+            const int rr = e / 6, cc = e - rr * 6;
+            const int row = 6 * c + cc, col = 6 * j + rr; /* lower-triangle entry = upper block (j, c) entry [rr][cc] */
+            if (col > row) continue;
+            const int ti = row >> 4, tj = col >> 4;
+            if (pass == 0) {
+                atomicAdd(&cnt[ti], 1);
+            } else {
+                const int pos = atomicAdd(&cnt[ti], 1);
+                const int mi = I[w.blk_mirror + bk];
+                const int d = ti - tj, slot = chb_base(M, d) + tj % chb_ring(M, d);
+                (void)efirst;
+                plan[chb_ent0(nb) + 2 * pos] = (mi * 36 + e) | ((I[w.blk_touch + mi] & 2) ? (int)0x80000000 : 0);
+                plan[chb_ent0(nb) + 2 * pos + 1] = slot * CHB_TILE + (row & 15) * CH_LD + (col & 15);
+            }
+        }
+        __syncthreads();
+        if (pass == 0) {
+            if (threadIdx.x == 0) { /* exclusive scan; cnt[] becomes the write cursor of pass 1 */
+                int acc = 0;
+                for (int i = 0; i < nb; i++) {
+                    const int c = cnt[i];
+                    plan[i] = acc;
+                    cnt[i] = acc;
+                    acc += c;
+                }
+                plan[nb] = acc;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int NT, bool TWO, int MAXM>
+__device__ __forceinline__ bool ba_chol_band(const BAWin &w, double *D, const int32_t *I, int n, double *dyn, double *bad_flag, int skip = 0) {
+    constexpr int NW = NT / 64;
+    constexpr int NTF = NT - 64;                 /* threads of the wavefronts beside the chain: they carry the fill */
+    constexpr int IPT = NT == 256 ? 8 : 4;       /* plan entries per such thread and step (more: a synchronous remainder loop) */
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int np = (n + 15) & ~15, nb = np >> 4, M = w.ch_pm >> 4;
+    double *A = D + w.A;     /* finished L tiles (dense row-major layout, only the band is touched) */
+    double *Li = D + w.Linv; /* inverse diagonal tiles */
+    const double *Sv = D + w.S, *S2v = D + w.S2;
+    const int32_t *plan = (const int32_t *)(D + w.fplan);
+    double *tiles = dyn;
+    double *sl = tiles + (size_t)chb_slots(M) * CHB_TILE; /* inverse of the current diagonal tile */
+    double *z = sl + CHB_TILE;
+    int32_t *efirst = (int32_t *)(z + np + 16), *elast = efirst + nb + 4, *pst = elast + nb + 4; /* LDS copies: nothing of the step bookkeeping waits for memory */
+    auto T = [&](int i, int j) -> double * {
+        const int d = i - j;
+        return tiles + (size_t)(chb_base(M, d) + j % chb_ring(M, d)) * CHB_TILE;
+    };
+    auto last_of = [&](int s) { return s < nb ? elast[s] : nb - 1; };
+    /* tile rows (r0, r1] enter: zero their tiles (columns efirst .. diagonal), identity on the padding rows */
+    auto zero_rows = [&](int r0, int r1) {
+        if (skip & 8) return;
+        for (int i = r0 + 1; i <= r1; i++) {
+            const int c0 = efirst[i];
+            for (int e = tid; e < (i - c0 + 1) * 256; e += NT) {
+                const int j = c0 + (e >> 8), r = (e >> 4) & 15, c = e & 15;
+                T(i, j)[r * CH_LD + c] = (j == i && r == c && i * 16 + r >= n) ? 1.0 : 0.0;
+            }
+        }
+    };
+    /* diagonal tile kb (in LDS): Cholesky factor and inverse by one wavefront in registers, as in ba_chol_solve */
+    auto factor_diag = [&](int kb) {
+        if (skip & 2) return;
+        const int rl = lane & 15;
+        const double *Td = T(kb, kb);
+        double a[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) a[k] = Td[rl * CH_LD + k];
+        bool bad = false;
+        double inv[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            double ajj = lane_bcast(a[j], j);
+            if (!(ajj > 0.0) || !isfinite(ajj)) {
+                bad = true;
+                ajj = 1.0;
+            }
+            double r = __builtin_amdgcn_rsq(ajj);
+#pragma unroll
+            for (int nr = 0; nr < 2; nr++) {
+                const double e = __builtin_fma(-(ajj * r), r, 1.0);
+                r = __builtin_fma(0.5 * r, e, r);
+            }
+            inv[j] = r;
+            const double pv = ajj * r;
+            a[j] = (rl == j) ? pv : a[j] * r;
+#pragma unroll
+            for (int k = j + 1; k < 16; k++) {
+                const double lkj = lane_bcast(a[j], k);
+                a[k] -= a[j] * lkj;
+            }
+        }
+        double x[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            double v = (i == rl) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if (k < i) v -= lane_bcast(a[k], i) * x[k];
+            x[i] = (i >= rl) ? v * inv[i] : 0.0;
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                sl[i * CH_LD + rl] = x[i];
+                Li[kb * 256 + i * 16 + rl] = x[i];
+            }
+        }
+        if (bad && lane == 0) bad_flag[0] = 1.0;
+    };
+    /* panel tile (gi, s): L = A L_ss^-T in place, and to memory for the backward substitution */
+    auto panel_tile = [&](int gi, int s) {
+        double *Tp = T(gi, s);
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) {
+            const double a = Tp[(lane & 15) * CH_LD + 4 * s4 + (lane >> 4)];
+            const double b = (4 * s4 + (lane >> 4) <= (lane & 15)) ? sl[(lane & 15) * CH_LD + 4 * s4 + (lane >> 4)] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = (lane >> 4) + 4 * r, col = lane & 15;
+            Tp[row * CH_LD + col] = acc[r];
+            A[(int64_t)(gi * 16 + row) * np + s * 16 + col] = acc[r];
+        }
+    };
+    /* trailing tile (gi, gj) -= L_(gi,s) L_(gj,s)^T, all three in LDS */
+    auto update_tile = [&](int gi, int gj, int s) {
+        double *C = T(gi, gj) + (lane >> 4) * CH_LD + (lane & 15);
+        const double *Pa = T(gi, s), *Pb = T(gj, s);
+        v4d c4;
+#pragma unroll
+        for (int r = 0; r < 4; r++) c4[r] = C[4 * r * CH_LD];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) {
+            const double a = -Pa[(lane & 15) * CH_LD + 4 * s4 + (lane >> 4)];
+            const double b = Pb[(lane & 15) * CH_LD + 4 * s4 + (lane >> 4)];
+            c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c4, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) C[4 * r * CH_LD] = c4[r];
+    };
+    auto s_value = [&](int src) -> double { /* entry of S (+ S2 where the second Schur part touched the block) */
+        const int si = src & 0x7fffffff;
+        double v = Sv[si];
+        if (TWO && src < 0) v += S2v[si];
+        return v;
+    };
+    /* plain (waiting) fill of plan entries [p0, p1) by `nthr` threads, this one being number t0 */
+    auto fill_now = [&](int p0, int p1, int t0, int nthr) {
+        if (skip & 1) return;
+        for (int q = p0 + t0; q < p1; q += nthr) {
+            const int2 en = ((const int2 *)(plan + chb_ent0(nb)))[q];
+            tiles[en.y] = s_value(en.x);
+        }
+    };
+
+    if (tid == 0) bad_flag[0] = 0.0;
+    for (int i = tid; i < nb; i += NT) {
+        efirst[i] = I[w.ch_first + i];
+        elast[i] = I[w.ch_last + i];
+    }
+    for (int i = tid; i <= nb; i += NT) pst[i] = plan[i];
+    for (int i = tid; i < np; i += NT) z[i] = (i < n) ? (TWO ? D[w.g + i] + D[w.g2 + i] : D[w.g + i]) : 0.0;
+    __syncthreads();
+    /* rows 0 .. elast[0] are in the window before step 0 */
+    zero_rows(-1, elast[0]);
+    __syncthreads();
+    fill_now(pst[0], pst[elast[0] + 1], tid, NT);
+    /* software pipeline of the fill, on the threads beside the chain: entA = plan entries of the rows that enter two
+       steps from now (stage A), val / offB = the S values / destinations of those that enter next step (stage B) */
+    int2 entA[IPT];
+    double val[IPT];
+    int offB[IPT];
+    int baseA = 0, endA = 0, baseB = 0, endB = 0; /* plan ranges of the stages */
+    const int tf = tid - 64;
+    auto stage_A = [&](int r0, int r1) { /* rows (r0, r1]: issue the plan loads */
+        baseA = pst[r0 + 1];
+        endA = pst[r1 + 1];
+        if (skip & 1) endA = baseA;
+#pragma unroll
+        for (int k = 0; k < IPT; k++) {
+            const int q = baseA + tf + k * NTF;
+            entA[k] = ((const int2 *)(plan + chb_ent0(nb)))[q < endA ? q : (baseA < endA ? baseA : 0)];
+        }
+    };
+    auto stage_B = [&]() { /* the entries of stage A have arrived: issue their S loads */
+        baseB = baseA;
+        endB = endA;
+#pragma unroll
+        for (int k = 0; k < IPT; k++) {
+            val[k] = (baseB + tf + k * NTF < endB) ? s_value(entA[k].x) : 0.0;
+            offB[k] = entA[k].y;
+        }
+    };
+    auto stage_C = [&]() { /* the values of stage B have arrived: into the (zeroed) tiles; what did not fit the registers, plainly */
+#pragma unroll
+        for (int k = 0; k < IPT; k++)
+            if (baseB + tf + k * NTF < endB) tiles[offB[k]] = val[k];
+        fill_now(baseB + IPT * NTF, endB, tf, NTF);
+    };
+    __syncthreads();
+    if (wave != 0) {
+        stage_A(elast[0], last_of(1));
+        stage_B();
+        stage_A(last_of(1), last_of(2));
+    } else {
+        factor_diag(0);
+    }
+    __syncthreads();
+    for (int s = 0; s < nb; s++) {
+        const int m = (skip & 16) ? 0 : elast[s] - s;
+        /* phase A: panel of column s; y_s; zero the rows that enter at this step */
+        for (int bi = wave; bi < m; bi += NW) panel_tile(s + 1 + bi, s);
+        if (wave == NW - 1) {
+            double y = 0.0;
+            if (lane < 16) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) y += sl[lane * CH_LD + k] * z[s * 16 + k]; /* (sl is zero above its diagonal) */
+            }
+            CH_WAVE_SYNC();
+            if (lane < 16) z[s * 16 + lane] = y;
+        }
+        zero_rows(elast[s], last_of(s + 1));
+        chb_barrier();
+        /* phase B: wavefront 0 carries the chain (next diagonal tile); the others the rest of the update, the forward
+           substitution and the fill pipeline */
+        if (wave == 0) {
+            if (m > 0) {
+                update_tile(s + 1, s + 1, s);
+                CH_WAVE_SYNC();
+            }
+            if (s + 1 < nb) factor_diag(s + 1);
+        } else {
+            const int ntile = m * (m + 1) / 2;
+            for (int t = wave; t < ntile; t += NW - 1) { /* tile t = (ii, jj), jj <= ii, row-major over the triangle; t = 0 is wavefront 0's */
+                int ii = 0;
+                while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
+                const int jj = t - ii * (ii + 1) / 2;
+                update_tile(s + 1 + ii, s + 1 + jj, s);
+            }
+            if (wave == NW - 1) { /* z_i -= L_(i,s) y_s: one lane per row of the panel (m <= 8: two rows per lane at most) */
+                for (int r = lane; r < m * 16; r += 64) {
+                    const double *Lr = T(s + 1 + (r >> 4), s) + (r & 15) * CH_LD;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 16; k++) acc += Lr[k] * z[s * 16 + k];
+                    z[(s + 1) * 16 + r] -= acc;
+                }
+            }
+            stage_C();                                 /* rows (elast[s], elast[s + 1]]: first used at step s + 1 */
+            stage_B();                                 /* rows (elast[s + 1], elast[s + 2]] */
+            stage_A(last_of(s + 2), last_of(s + 3));
+        }
+        chb_barrier();
+    }
+    __syncthreads(); /* (a full one: the L tiles and inverse diagonal tiles written above are read below) */
+    const bool ok = bad_flag[0] == 0.0;
+    /* backward substitution L^T x = y, row by row from the bottom; row i belongs to wavefront i mod NW */
+    if (!(skip & 4)) {
+        constexpr int CPL = (MAXM * 16 + 63) / 64; /* envelope columns of a row per lane (MAXM: widest band of the instantiation) */
+        double rowv[CPL][16], liv[16];
+        auto load_row = [&](int i) {
+            const int c0 = efirst[i] * 16, ncol = i * 16 - c0;
+#pragma unroll
+            for (int q = 0; q < CPL; q++) {
+                const int j = lane + 64 * q;
+#pragma unroll
+                for (int r = 0; r < 16; r++) rowv[q][r] = j < ncol ? A[(int64_t)(i * 16 + r) * np + c0 + j] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) liv[k] = Li[i * 256 + k * 16 + (lane & 15)];
+        };
+        int mine = nb - 1 - ((nb - 1 - wave) % NW + NW) % NW; /* the last row i with i mod NW == wave */
+        if (mine >= 0) load_row(mine);
+        for (int i = nb - 1; i >= 0; i--) {
+            if (i == mine) {
+                double x = 0.0;
+#pragma unroll
+                for (int k = 0; k < 16; k++) x += liv[k] * z[i * 16 + k]; /* x_i[c] = sum_k Linv[k][c] z_i[k] */
+                CH_WAVE_SYNC();
+                if (lane < 16) z[i * 16 + lane] = x;
+                CH_WAVE_SYNC();
+                const int c0 = efirst[i] * 16, ncol = i * 16 - c0;
+#pragma unroll
+                for (int q = 0; q < CPL; q++) {
+                    const int j = lane + 64 * q;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc += rowv[q][r] * z[i * 16 + r];
+                    if (j < ncol) z[c0 + j] -= acc;
+                }
+                mine -= NW;
+                if (mine >= 0) load_row(mine);
+            }
+            chb_barrier();
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += NT) D[w.x + i] = ok ? z[i] : 0.0;
     return ok;
 }
 
@@ -2356,6 +2731,19 @@ __global__ __launch_bounds__(BA_T) void k_ba_ph_chol(BABufs bufs) {
     if (ph == 2.0) return;
     ba_ph_chol(w, D, I, ba_dyn, bad_flag);
 }
+/* the band Cholesky (ba_chol_band) as a phase kernel: NT threads per window, bands up to MAXM tile rows */
+template <int NT, int MAXM>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void k_ba_ph_chol_band(BABufs bufs, int skip) {
+    extern __shared__ __attribute__((aligned(16))) double ba_dyn[];
+    __shared__ double bad_flag[1];
+    BA_PH_WINDOW_COPY
+    if (ph == 2.0) return;
+    const bool ok2 = ba_chol_band<NT, true, MAXM>(w, D, I, w.Ncf * 6, ba_dyn, bad_flag, skip);
+    if (threadIdx.x == 0) {
+        D[w.st + ST_OK2] = ok2 ? 1.0 : 0.0;
+        D[w.st + ST_SOLVES] += 1.0;
+    }
+}
 __global__ __launch_bounds__(BA_PH_T) void k_ba_ph_backsub(BABufs bufs) {
     __shared__ BARed s;
     BA_PH_WINDOW_COPY
@@ -2934,9 +3322,17 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hO, std::vecto
         if (((size_t)w.ch_pm * 17 + 2 * 16 * 17 + np) * 8 <= BA_CHOL_LDS_BYTES) {
             w.A = allocS(np * np);
             w.Linv = allocS((np / 16) * 256);
+            /* fill plan of the band Cholesky: nb + 1 starts and two ints per lower-triangle scalar of S (device-built, scratch) */
+            w.fplan = -1;
+            if (maxm <= CHB_MAX_M && nbt <= CHB_MAX_NB && (size_t)nnzb * 36 < (1u << 30)) {
+                size_t nlow = 0;
+                for (int i = 0; i < nnzb; i++) nlow += bmirror[i] > i ? 1 : 0; /* strictly upper blocks = strictly lower ones */
+                w.fplan = allocS(((size_t)chb_ent0(nbt) + 2 * (nlow * 36 + (size_t)Ncf * 21)) / 2 + 2);
+            }
         } else {
             w.ch_pm = -1; /* marks "no Cholesky" for the kernel and the launch code */
             w.A = w.Linv = 0;
+            w.fplan = -1;
         }
         w.ch_first = putI(first);
         w.ch_last = putI(last);
@@ -3288,6 +3684,7 @@ static int ba_stage(BASolver *s, BAJob &J, const BAProblem *probs, BAResult *res
         for (auto f : kIntFields) w.*f += (int64_t)oI[i];
         w.flags += (int64_t)oB[i];
         for (auto f : kScratchFields) w.*f += (int64_t)(nO + nD + scratchD);
+        if (w.fplan >= 0) w.fplan += (int64_t)(nO + nD + scratchD); /* (-1: the window has no fill plan) */
         scratchD += pieces[i].scratch;
         J.wins[i] = w;
     }
@@ -3381,6 +3778,31 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
         static const int schur_skip = getenv("ORBSLAM_AMD_BA_SCHUR_SKIP") ? atoi(getenv("ORBSLAM_AMD_BA_SCHUR_SKIP")) : 0; /* timing experiments (results invalid) */
         BCHK(lim_schur.ensure((const void *)k_ba_ph_schur2, (size_t)BA_CHUNK_DOUBLES * 8));
         BCHK(lim_chol.ensure((const void *)k_ba_ph_chol, chol_doubles * 8));
+        /* band Cholesky with the LDS-resident window (ba_chol_band) when every window's band is narrow enough; 256 threads
+           per window -- two windows per CU -- once the batch can fill the device that way.  ORBSLAM_AMD_BA_CHOL_BAND=0:
+           the round-2 kernel; ORBSLAM_AMD_BA_CHOL_NT=256 / 512 forces the workgroup size (tests, measurements). */
+        static const int band_env = getenv("ORBSLAM_AMD_BA_CHOL_BAND") ? atoi(getenv("ORBSLAM_AMD_BA_CHOL_BAND")) : 1;
+        static const int band_nt_env = getenv("ORBSLAM_AMD_BA_CHOL_NT") ? atoi(getenv("ORBSLAM_AMD_BA_CHOL_NT")) : 0;
+        static const int band_skip = getenv("ORBSLAM_AMD_BA_CHOL_SKIP") ? atoi(getenv("ORBSLAM_AMD_BA_CHOL_SKIP")) : 0; /* timing experiments (results invalid) */
+        size_t band_doubles = 0;
+        int band_maxm = 0;
+        bool band = band_env != 0;
+        for (int i = 0; i < nwin && band; i++) {
+            const BAWin &w = J.wins[i];
+            const int M = w.ch_pm / 16;
+            if (M < 1 || M > CHB_MAX_M || w.fplan < 0) band = false;
+            band_maxm = std::max(band_maxm, M);
+            band_doubles = std::max(band_doubles, chb_lds_doubles(M, (w.Ncf * 6 + 15) & ~15));
+        }
+        if (band_doubles * 8 > (size_t)BA_CHOL_LDS_BYTES) band = false;
+        int band_nt = (nwin >= 2 * s->cu_count - s->cu_count / 4 && band_doubles * 8 <= 72 * 1024) ? 256 : 512;
+        if (band_nt_env == 256 || band_nt_env == 512) band_nt = band_nt_env;
+        const void *band_fn = band_nt == 256 ? (band_maxm <= 4 ? (const void *)k_ba_ph_chol_band<256, 4> : (const void *)k_ba_ph_chol_band<256, 8>)
+                                             : (band_maxm <= 4 ? (const void *)k_ba_ph_chol_band<512, 4> : (const void *)k_ba_ph_chol_band<512, 8>);
+        if (band) {
+            static PerDeviceLdsLimit lim_band[4];
+            BCHK(lim_band[(band_nt == 256 ? 0 : 2) + (band_maxm <= 4 ? 0 : 1)].ensure(band_fn, band_doubles * 8));
+        }
         const size_t fin_doubles = std::max<size_t>(chol_doubles, 2 * (size_t)BA_CHUNK_DOUBLES);
         BCHK(lim_fin.ensure((const void *)k_ba_ph_finish, fin_doubles * 8));
         static const bool phase_prof = getenv("ORBSLAM_AMD_BA_PHASE_PROF") != nullptr; /* diagnostics: serialises the phases */
@@ -3422,6 +3844,10 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
         const int parts_lists = std::max(1, std::min(16, (max_nub + 4 * BA_W - 1) / (4 * BA_W))); /* four blocks per wavefront and step */
         const int partsC = std::max(1, (maxC + BA_PH_T / 64 - 1) / (BA_PH_T / 64));
         int trial_seq = 0;
+        if (band) { /* once per batch: the windows' patterns do not change between trials */
+            hipLaunchKernelGGL(k_ba_ph_fillplan, dim3(nwin), dim3(256), 0, ks, bufs);
+            BCHK(hipGetLastError());
+        }
         for (int round = 0; round < P0.n_rounds; round++) {
             const int nit = P0.rounds[round];
             if (s->profiling) BCHK(hipEventRecord(J.prof_ev[2 * J.prof_launches], ks));
@@ -3444,7 +3870,19 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
                     return rc;
                 if (any_lists)
                     if ((rc = timed(4, [&] { hipLaunchKernelGGL(k_ba_ph_schur_lists, dim3(nwin, parts_lists), dim3(BA_T), 0, ks, bufs); }))) return rc;
-                if ((rc = timed(5, [&] { hipLaunchKernelGGL(k_ba_ph_chol, dim3(nwin), dim3(BA_T), chol_doubles * 8, ks, bufs); }))) return rc;
+                if ((rc = timed(5, [&] {
+                         if (!band)
+                             hipLaunchKernelGGL(k_ba_ph_chol, dim3(nwin), dim3(BA_T), chol_doubles * 8, ks, bufs);
+                         else if (band_nt == 256 && band_maxm <= 4)
+                             hipLaunchKernelGGL((k_ba_ph_chol_band<256, 4>), dim3(nwin), dim3(256), band_doubles * 8, ks, bufs, band_skip);
+                         else if (band_nt == 256)
+                             hipLaunchKernelGGL((k_ba_ph_chol_band<256, 8>), dim3(nwin), dim3(256), band_doubles * 8, ks, bufs, band_skip);
+                         else if (band_maxm <= 4)
+                             hipLaunchKernelGGL((k_ba_ph_chol_band<512, 4>), dim3(nwin), dim3(512), band_doubles * 8, ks, bufs, band_skip);
+                         else
+                             hipLaunchKernelGGL((k_ba_ph_chol_band<512, 8>), dim3(nwin), dim3(512), band_doubles * 8, ks, bufs, band_skip);
+                     })))
+                    return rc;
                 if ((rc = timed(6, [&] { hipLaunchKernelGGL(k_ba_ph_backsub, gP, tb, 0, ks, bufs); }))) return rc;
                 if ((rc = timed(7, [&] { hipLaunchKernelGGL(k_ba_ph_trial, gE, tb, 0, ks, bufs); }))) return rc;
                 if ((rc = timed(8, [&] {
