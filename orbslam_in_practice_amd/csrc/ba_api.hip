@@ -3558,6 +3558,14 @@ template <typename T> static int ba_grow_pinned(T *&p, size_t &cap, size_t need)
 
 static double ba_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+/* host threads of the staging / unpacking pools.  A one-GPU box has a CPU share of 16 (cgroup quota per 100 ms), but staging
+   comes in bursts -- 24 ms of 16 threads per 256-window batch, then nothing until the next batch -- and a burst may run wider
+   than the share as long as the period's budget holds: 32 threads measured 7050 windows/s streamed against 6320 with 16 (64:
+   7490, too close to the quota to be the default).  ORBSLAM_AMD_BA_HOST_THREADS overrides. */
+static int ba_host_threads() {
+    static const int n = getenv("ORBSLAM_AMD_BA_HOST_THREADS") ? std::max(1, atoi(getenv("ORBSLAM_AMD_BA_HOST_THREADS"))) : 32;
+    return n;
+}
 template <class F> static void ba_parallel(int nthr, F &&f) {
     if (nthr <= 1) {
         f(0);
@@ -3634,7 +3642,7 @@ static int ba_stage(BASolver *s, BAJob &J, const BAProblem *probs, BAResult *res
     const int mean_limit = total_obs * 144 <= (size_t)BA_CACHED_W_BYTES ? BA_CHUNK_MEAN_TRACK_CACHED : BA_CHUNK_MEAN_TRACK;
     if ((int)s->pieces.size() < nwin) s->pieces.resize(nwin);
     std::vector<BAPiece> &pieces = s->pieces;
-    const int nthr = std::max(1, std::min<int>(nwin, std::min<int>(16, (int)std::thread::hardware_concurrency())));
+    const int nthr = std::max(1, std::min<int>(nwin, std::min<int>(ba_host_threads(), (int)std::thread::hardware_concurrency())));
     ba_parallel(nthr, [&](int t) {
         for (int i = t; i < nwin; i += nthr) {
             BAPiece &pc = pieces[i];
@@ -3970,7 +3978,7 @@ static int ba_finish(BASolver *s, BAJob &J) {
     const double t_done = ba_now();
     const int nwin = J.nwin;
     BAResult *res = J.res;
-    const int nt = std::max(1, std::min<int>(nwin / 8, std::min<int>(16, (int)std::thread::hardware_concurrency())));
+    const int nt = std::max(1, std::min<int>(nwin / 8, std::min<int>(ba_host_threads(), (int)std::thread::hardware_concurrency())));
     ba_parallel(nt, [&](int t) {
         for (int i = t; i < nwin; i += nt) {
             const BAWin &w = J.wins[i];

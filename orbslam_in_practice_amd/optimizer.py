@@ -35,15 +35,21 @@ class Optimizer:
         except Exception:
             pass
 
+    _ARRAYS = (("poses", np.float64), ("fixed", np.uint8), ("points", np.float64), ("obs", np.float64),
+               ("cam_idx", np.int32), ("pt_idx", np.int32), ("inv_sigma2", np.float64))
+
     @staticmethod
     def _fill(P, w, rounds, robust, chi2_threshold, drop_robust_after, stop):
-        keep = dict(poses=np.ascontiguousarray(w["poses"], np.float64),
-                    fixed=np.ascontiguousarray(w["fixed"], np.uint8),
-                    points=np.ascontiguousarray(w["points"], np.float64),
-                    obs=np.ascontiguousarray(w["obs"], np.float64),
-                    cam_idx=np.ascontiguousarray(w["cam_idx"], np.int32),
-                    pt_idx=np.ascontiguousarray(w["pt_idx"], np.int32),
-                    inv_sigma2=np.ascontiguousarray(w["inv_sigma2"], np.float64))
+        """fill the C struct of one window.  The filled struct is remembered ON the window dict (key "_abi"): a caller
+        that submits the same window object again (a stream of batches over a fixed set of windows, a retry) pays one
+        memmove instead of twenty ctypes attribute stores -- 7 ms per 256-window batch otherwise, a fifth of what the
+        device needs for the batch.  The memo is void as soon as any array of the window was replaced."""
+        key = (tuple(int(r) for r in rounds), bool(robust), float(chi2_threshold), int(drop_robust_after))
+        memo = w.get("_abi") if stop is None else None
+        if memo is not None and memo[0] == key and all(w[k] is memo[3][i] for i, (k, _) in enumerate(Optimizer._ARRAYS)):
+            C.memmove(C.byref(P), C.byref(memo[1]), C.sizeof(BAProblem))
+            return memo[2]
+        keep = {k: np.ascontiguousarray(w[k], dt) for k, dt in Optimizer._ARRAYS}
         P.n_cams, P.n_points, P.n_obs = len(keep["poses"]), len(keep["points"]), len(keep["obs"])
         for k, v in keep.items():
             setattr(P, k, v.ctypes.data)
@@ -55,6 +61,10 @@ class Optimizer:
         P.chi2_threshold = chi2_threshold
         P.drop_robust_after = drop_robust_after
         P.stop = stop.ctypes.data if stop is not None else None
+        if stop is None and isinstance(w, dict):
+            snap = BAProblem()
+            C.memmove(C.byref(snap), C.byref(P), C.sizeof(BAProblem))
+            w["_abi"] = (key, snap, keep, tuple(w[k] for k, _ in Optimizer._ARRAYS))
         return keep
 
     def _prepare(self, windows, rounds, robust, chi2_threshold, drop_robust_after, stop):
