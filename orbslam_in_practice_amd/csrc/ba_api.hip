@@ -819,7 +819,7 @@ __host__ __device__ __forceinline__ int chb_slots(int M) { return chb_base(M, M 
 __host__ __device__ __forceinline__ int chb_ent0(int nb) { return (nb + 2) & ~1; } /* first entry of a fill plan, in ints (8-byte aligned) */
 /* doubles of dynamic LDS: tile rings, inverse of the current diagonal tile, z, and (as ints) efirst / elast / plan starts */
 __host__ __device__ __forceinline__ size_t chb_lds_doubles(int M, int np) {
-    return (size_t)chb_slots(M) * CHB_TILE + CHB_TILE + np + 16 + (3 * (size_t)(np / 16 + 4) + 1) / 2;
+    return (size_t)chb_slots(M) * CHB_TILE + 2 * CHB_TILE + np + 16 + ((3 + (size_t)M + 1) * (size_t)(np / 16 + 4) + 1) / 2;
 }
 /* workgroup barrier that waits for this wave's LDS operations only: global loads issued before it stay in flight */
 __device__ __forceinline__ void chb_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -885,12 +885,16 @@ __device__ __forceinline__ bool ba_chol_band(const BAWin &w, double *D, const in
     const double *Sv = D + w.S, *S2v = D + w.S2;
     const int32_t *plan = (const int32_t *)(D + w.fplan);
     double *tiles = dyn;
-    double *sl = tiles + (size_t)chb_slots(M) * CHB_TILE; /* inverse of the current diagonal tile */
-    double *z = sl + CHB_TILE;
+    double *sl2 = tiles + (size_t)chb_slots(M) * CHB_TILE; /* inverses of the diagonal tiles of the current and the next step (s & 1) */
+    double *z = sl2 + 2 * CHB_TILE;
     int32_t *efirst = (int32_t *)(z + np + 16), *elast = efirst + nb + 4, *pst = elast + nb + 4; /* LDS copies: nothing of the step bookkeeping waits for memory */
+    int32_t *rpos = pst + nb + 4; /* rpos[d * (M + 2) + (j mod (M + 2))]... see T(): ring position of column j on diagonal d, as a table */
+    /* tile (i, j): ring d = i - j, position j mod (M + 2 - d).  The modulus is a run-time value (an integer division per
+       tile address otherwise): columns advance by one per step, so the position of column j is looked up in a table indexed
+       by d and j mod LCMLEN -- with LCMLEN = nb rounded up the table is simply indexed by j */
     auto T = [&](int i, int j) -> double * {
         const int d = i - j;
-        return tiles + (size_t)(chb_base(M, d) + j % chb_ring(M, d)) * CHB_TILE;
+        return tiles + rpos[d * nb + j];
     };
     auto last_of = [&](int s) { return s < nb ? elast[s] : nb - 1; };
     /* tile rows (r0, r1] enter: zero their tiles (columns efirst .. diagonal), identity on the padding rows */
@@ -900,13 +904,14 @@ __device__ __forceinline__ bool ba_chol_band(const BAWin &w, double *D, const in
             const int c0 = efirst[i];
             for (int e = tid; e < (i - c0 + 1) * 256; e += NT) {
                 const int j = c0 + (e >> 8), r = (e >> 4) & 15, c = e & 15;
-                T(i, j)[r * CH_LD + c] = (j == i && r == c && i * 16 + r >= n) ? 1.0 : 0.0;
+                tiles[rpos[(i - j) * nb + j] + r * CH_LD + c] = (j == i && r == c && i * 16 + r >= n) ? 1.0 : 0.0;
             }
         }
     };
     /* diagonal tile kb (in LDS): Cholesky factor and inverse by one wavefront in registers, as in ba_chol_solve */
     auto factor_diag = [&](int kb) {
         if (skip & 2) return;
+        double *sl = sl2 + (kb & 1) * CHB_TILE;
         const int rl = lane & 15;
         const double *Td = T(kb, kb);
         double a[16];
@@ -936,13 +941,22 @@ __device__ __forceinline__ bool ba_chol_band(const BAWin &w, double *D, const in
                 a[k] -= a[j] * lkj;
             }
         }
+        /* the inverse: column rl of L^-1 by forward substitution, x[i] = (delta - sum_{k<i} l[i][k] x[k]) / l[i][i].  Its 120
+           entries of L travel through LDS -- written once, read as broadcasts (every lane the same address) -- instead of
+           through 240 v_readlane on the wavefront that carries the factorisation's chain */
+        double *Ld = T(kb, kb); /* the tile's own slot: nobody else reads it before the step barrier */
+        if (lane < 16) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) Ld[rl * CH_LD + k] = a[k];
+        }
+        CH_WAVE_SYNC();
         double x[16];
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             double v = (i == rl) ? 1.0 : 0.0;
 #pragma unroll
             for (int k = 0; k < 16; k++)
-                if (k < i) v -= lane_bcast(a[k], i) * x[k];
+                if (k < i) v -= Ld[i * CH_LD + k] * x[k];
             x[i] = (i >= rl) ? v * inv[i] : 0.0;
         }
         if (lane < 16) {
@@ -956,6 +970,7 @@ __device__ __forceinline__ bool ba_chol_band(const BAWin &w, double *D, const in
     };
     /* panel tile (gi, s): L = A L_ss^-T in place, and to memory for the backward substitution */
     auto panel_tile = [&](int gi, int s) {
+        const double *sl = sl2 + (s & 1) * CHB_TILE;
         double *Tp = T(gi, s);
         v4d acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -1008,6 +1023,10 @@ __device__ __forceinline__ bool ba_chol_band(const BAWin &w, double *D, const in
         elast[i] = I[w.ch_last + i];
     }
     for (int i = tid; i <= nb; i += NT) pst[i] = plan[i];
+    for (int i = tid; i < (M + 1) * nb; i += NT) {
+        const int d = i / nb, j = i - d * nb;
+        rpos[i] = (chb_base(M, d) + j % chb_ring(M, d)) * CHB_TILE;
+    }
     for (int i = tid; i < np; i += NT) z[i] = (i < n) ? (TWO ? D[w.g + i] + D[w.g2 + i] : D[w.g + i]) : 0.0;
     __syncthreads();
     /* rows 0 .. elast[0] are in the window before step 0 */
@@ -1059,15 +1078,6 @@ __device__ __forceinline__ bool ba_chol_band(const BAWin &w, double *D, const in
         const int m = (skip & 16) ? 0 : elast[s] - s;
         /* phase A: panel of column s; y_s; zero the rows that enter at this step */
         for (int bi = wave; bi < m; bi += NW) panel_tile(s + 1 + bi, s);
-        if (wave == NW - 1) {
-            double y = 0.0;
-            if (lane < 16) {
-#pragma unroll
-                for (int k = 0; k < 16; k++) y += sl[lane * CH_LD + k] * z[s * 16 + k]; /* (sl is zero above its diagonal) */
-            }
-            CH_WAVE_SYNC();
-            if (lane < 16) z[s * 16 + lane] = y;
-        }
         zero_rows(elast[s], last_of(s + 1));
         chb_barrier();
         /* phase B: wavefront 0 carries the chain (next diagonal tile); the others the rest of the update, the forward
@@ -1086,7 +1096,16 @@ __device__ __forceinline__ bool ba_chol_band(const BAWin &w, double *D, const in
                 const int jj = t - ii * (ii + 1) / 2;
                 update_tile(s + 1 + ii, s + 1 + jj, s);
             }
-            if (wave == NW - 1) { /* z_i -= L_(i,s) y_s: one lane per row of the panel (m <= 8: two rows per lane at most) */
+            if (wave == NW - 1) { /* y_s = L_ss^-1 z_s, then z_i -= L_(i,s) y_s: one lane per row of the panel (m <= 8: two rows per lane at most) */
+                const double *sl = sl2 + (s & 1) * CHB_TILE; /* (the chain wavefront is writing the OTHER inverse meanwhile) */
+                double ys = 0.0;
+                if (lane < 16) {
+#pragma unroll
+                    for (int k = 0; k < 16; k++) ys += sl[lane * CH_LD + k] * z[s * 16 + k]; /* (sl is zero above its diagonal) */
+                }
+                CH_WAVE_SYNC();
+                if (lane < 16) z[s * 16 + lane] = ys;
+                CH_WAVE_SYNC();
                 for (int r = lane; r < m * 16; r += 64) {
                     const double *Lr = T(s + 1 + (r >> 4), s) + (r & 15) * CH_LD;
                     double acc = 0.0;
@@ -1146,6 +1165,14 @@ __device__ __forceinline__ bool ba_chol_band(const BAWin &w, double *D, const in
     __syncthreads();
     for (int i = tid; i < n; i += NT) D[w.x + i] = ok ? z[i] : 0.0;
     return ok;
+}
+
+/* out-of-line instances for the fused kernel (k_ba_iteration: 512 threads; S only -- no second Schur accumulator there) */
+__device__ __noinline__ bool ba_chol_band_fused4(const BAWin &w, double *D, const int32_t *I, int n, double *dyn, double *bad_flag) {
+    return ba_chol_band<BA_T, false, 4>(w, D, I, n, dyn, bad_flag);
+}
+__device__ __noinline__ bool ba_chol_band_fused8(const BAWin &w, double *D, const int32_t *I, int n, double *dyn, double *bad_flag) {
+    return ba_chol_band<BA_T, false, 8>(w, D, I, n, dyn, bad_flag);
 }
 
 /* Schur complement, batch path (one workgroup per window).
@@ -1869,7 +1896,7 @@ __device__ __forceinline__ void ba_phase_accept(const BAWin &w, double *D, int g
  * which a launch per iteration did -- the launch lasted as long as its slowest window). */
 __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of_round, double pcg_tol2, int pcg_maxit,
                                                        int debug, int solver, int dyn_doubles, int G, int launch_seq,
-                                                       int n_iters) {
+                                                       int n_iters, int band) {
     __shared__ BAShared s;
     extern __shared__ __attribute__((aligned(16))) double ba_dyn[];
     /* workgroups [win * G, win * G + G) are the team of window `win` */
@@ -1966,6 +1993,10 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
         BA_STAMP(5)
         const int np_ = (n + 15) & ~15;
         const bool use_chol = solver == 1 && n > 0 && w.ch_pm > 0 && (w.ch_pm * CH_LD + 2 * 16 * CH_LD + np_) <= dyn_doubles;
+        /* band Cholesky with the LDS-resident window (ba_chol_band): no dense matrix to assemble, the lead workgroup fills its
+           tiles straight from S.  `band` (a launch argument) says that the fill plans exist (k_ba_ph_fillplan has run). */
+        const bool use_band = use_chol && band && debug <= 1 && w.fplan >= 0 && (w.ch_pm >> 4) <= CHB_MAX_M &&
+                              chb_lds_doubles(w.ch_pm >> 4, np_) <= (size_t)dyn_doubles;
         if (!use_chol || debug > 1) {
             /* the Cholesky reads the upper blocks only; PCG (and the debug residual) need the full symmetric S */
             for (int i = gtid; i < w.nnzb * 36; i += gthreads) {
@@ -1975,7 +2006,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
             }
             team_sync(team, s);
         }
-        if (use_chol) { /* dense matrix of the reduced system: assembled by the whole team */
+        if (use_chol && !use_band) { /* dense matrix of the reduced system: assembled by the whole team */
             ba_chol_assemble(w, D, I, n, gtid, gthreads, gwave, gwaves, [&] { team_sync(team, s); });
             team_sync(team, s);
         }
@@ -1986,7 +2017,10 @@ __global__ __launch_bounds__(BA_T) void k_ba_iteration(BABufs bufs, int first_of
            PCG otherwise / on request */
         if (use_chol) {
             BA_STAMP(5)
-            ok2 = G > 1 ? ba_chol_solve<false, true>(w, D, I, n, ba_dyn, &s.bc[0], debug) : ba_chol_solve<false, false>(w, D, I, n, ba_dyn, &s.bc[0], debug);
+            if (use_band)
+                ok2 = (w.ch_pm >> 4) <= 4 ? ba_chol_band_fused4(w, D, I, n, ba_dyn, &s.bc[0]) : ba_chol_band_fused8(w, D, I, n, ba_dyn, &s.bc[0]);
+            else
+                ok2 = G > 1 ? ba_chol_solve<false, true>(w, D, I, n, ba_dyn, &s.bc[0], debug) : ba_chol_solve<false, false>(w, D, I, n, ba_dyn, &s.bc[0], debug);
             solves++;
             if (debug > 1) { /* residual of the direct solve against the block-sparse S */
                 double r2 = 0, g2 = 0;
@@ -3745,6 +3779,23 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
     }
     for (int i = 0; i < nwin; i++) /* the LDS tiles of the chunked Schur pass share the region with the Cholesky panel */
         if (J.team == 1 && J.wins[i].nchunks > 0) dyn_doubles = std::max(dyn_doubles, (int)BA_CHUNK_DOUBLES);
+    /* the band Cholesky (LDS-resident window, ba_chol_band) inside the fused kernel: when every window with a dense matrix has
+       a fill plan and a narrow band; its window must fit beside the static LDS (ORBSLAM_AMD_BA_CHOL_BAND=0: round 2's solver) */
+    static const int fused_band_env = getenv("ORBSLAM_AMD_BA_CHOL_BAND") ? atoi(getenv("ORBSLAM_AMD_BA_CHOL_BAND")) : 1;
+    int fused_band = s->solver == 1 && fused_band_env != 0 ? 1 : 0;
+    {
+        size_t need = 0;
+        bool any = false;
+        for (int i = 0; i < nwin && fused_band; i++) {
+            const BAWin &w = J.wins[i];
+            if (w.ch_pm <= 0) continue;
+            if (w.fplan < 0 || (w.ch_pm >> 4) > CHB_MAX_M) fused_band = 0;
+            need = std::max(need, chb_lds_doubles(w.ch_pm >> 4, (w.Ncf * 6 + 15) & ~15));
+            any = true;
+        }
+        if (!any || need * 8 > (size_t)BA_CHOL_LDS_BYTES) fused_band = 0;
+        if (fused_band) dyn_doubles = std::max(dyn_doubles, (int)need);
+    }
     {
         static PerDeviceLdsLimit lim;
         BCHK(lim.ensure((const void *)k_ba_iteration, (size_t)dyn_doubles * 8));
@@ -3915,6 +3966,10 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
             (void)hipEventDestroy(pe1);
         }
     }
+    if (!split && fused_band) { /* once per batch: the fill plans of the band Cholesky */
+        hipLaunchKernelGGL(k_ba_ph_fillplan, dim3(nwin), dim3(256), 0, ks, bufs);
+        BCHK(hipGetLastError());
+    }
     for (int round = 0; round < P0.n_rounds && !halted && !split; round++) {
         /* one launch per optimize() round; per iteration only when the host has a stop flag to poll in between */
         const int per_launch = any_stop_ptr ? 1 : std::max(P0.rounds[round], 1);
@@ -3932,16 +3987,16 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
             if (G > 1 && !no_coop) {
                 /* a team needs all its workgroups resident at once: cooperative launch (the runtime checks the grid
                    against the device and never runs two cooperative kernels side by side) */
-                void *args[] = {&bufs, &first, &tol2, &pcg_maxit, &dbg, &solver, &dyn_doubles, &g, &sq, &nit};
+                void *args[] = {&bufs, &first, &tol2, &pcg_maxit, &dbg, &solver, &dyn_doubles, &g, &sq, &nit, &fused_band};
                 BCHK(hipLaunchCooperativeKernel((const void *)k_ba_iteration, dim3(nwin * G), dim3(BA_T), args,
                                                 (size_t)dyn_doubles * 8, ks));
             } else if (G > 1) {
                 hipLaunchKernelGGL(k_ba_iteration, dim3(nwin * G), dim3(BA_T), (size_t)dyn_doubles * 8, ks, bufs, first, tol2,
-                                   pcg_maxit, dbg, solver, dyn_doubles, g, sq, nit);
+                                   pcg_maxit, dbg, solver, dyn_doubles, g, sq, nit, fused_band);
                 BCHK(hipGetLastError());
             } else {
                 hipLaunchKernelGGL(k_ba_iteration, dim3(nwin), dim3(BA_T), (size_t)dyn_doubles * 8, ks, bufs, first, tol2,
-                                   pcg_maxit, dbg, solver, dyn_doubles, 1, sq, nit);
+                                   pcg_maxit, dbg, solver, dyn_doubles, 1, sq, nit, fused_band);
                 BCHK(hipGetLastError());
             }
             if (s->profiling) BCHK(hipEventRecord(J.prof_ev[2 * J.prof_launches + 1], ks));
