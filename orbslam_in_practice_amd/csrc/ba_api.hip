@@ -926,11 +926,13 @@ __device__ __forceinline__ bool ba_chol_band(const BAWin &w, double *D, const in
                 bad = true;
                 ajj = 1.0;
             }
+            /* 1 / sqrt(ajj): v_rsq_f64 (about 2^-23) and ONE step of the cubically convergent iteration
+               r (1 + e / 2 + 3 e^2 / 8), e = 1 - ajj r^2 (error ~ e^3: below 2^-60) -- five dependent f64 operations where
+               two Newton steps are eight; f64 issues at half rate, and this wavefront IS the solver's chain */
             double r = __builtin_amdgcn_rsq(ajj);
-#pragma unroll
-            for (int nr = 0; nr < 2; nr++) {
+            {
                 const double e = __builtin_fma(-(ajj * r), r, 1.0);
-                r = __builtin_fma(0.5 * r, e, r);
+                r = __builtin_fma(r, __builtin_fma(0.375, e, 0.5) * e, r);
             }
             inv[j] = r;
             const double pv = ajj * r;
@@ -938,7 +940,7 @@ __device__ __forceinline__ bool ba_chol_band(const BAWin &w, double *D, const in
 #pragma unroll
             for (int k = j + 1; k < 16; k++) {
                 const double lkj = lane_bcast(a[j], k);
-                a[k] -= a[j] * lkj;
+                a[k] = __builtin_fma(-a[j], lkj, a[k]); /* (one instruction: the translation unit is built with -ffp-contract=off) */
             }
         }
         /* the inverse: column rl of L^-1 by forward substitution, x[i] = (delta - sum_{k<i} l[i][k] x[k]) / l[i][i].  Its 120
@@ -956,7 +958,7 @@ __device__ __forceinline__ bool ba_chol_band(const BAWin &w, double *D, const in
             double v = (i == rl) ? 1.0 : 0.0;
 #pragma unroll
             for (int k = 0; k < 16; k++)
-                if (k < i) v -= Ld[i * CH_LD + k] * x[k];
+                if (k < i) v = __builtin_fma(-Ld[i * CH_LD + k], x[k], v);
             x[i] = (i >= rl) ? v * inv[i] : 0.0;
         }
         if (lane < 16) {
@@ -1074,12 +1076,23 @@ __device__ __forceinline__ bool ba_chol_band(const BAWin &w, double *D, const in
         factor_diag(0);
     }
     __syncthreads();
+    /* (skip & 32: wavefront 0 times its own sections -- s_memrealtime ticks of 10 ns -- and prints them; diagnostics) */
+    unsigned long long tA = 0, tbA = 0, tU = 0, tF = 0, tbB = 0, t0 = 0, t1;
+#define CHB_T(acc)                                      \
+    if (skip & 32) {                                    \
+        t1 = __builtin_amdgcn_s_memrealtime();          \
+        acc += t1 - t0;                                 \
+        t0 = t1;                                        \
+    }
+    if (skip & 32) t0 = __builtin_amdgcn_s_memrealtime();
     for (int s = 0; s < nb; s++) {
         const int m = (skip & 16) ? 0 : elast[s] - s;
         /* phase A: panel of column s; y_s; zero the rows that enter at this step */
         for (int bi = wave; bi < m; bi += NW) panel_tile(s + 1 + bi, s);
         zero_rows(elast[s], last_of(s + 1));
+        CHB_T(tA)
         chb_barrier();
+        CHB_T(tbA)
         /* phase B: wavefront 0 carries the chain (next diagonal tile); the others the rest of the update, the forward
            substitution and the fill pipeline */
         if (wave == 0) {
@@ -1087,7 +1100,9 @@ __device__ __forceinline__ bool ba_chol_band(const BAWin &w, double *D, const in
                 update_tile(s + 1, s + 1, s);
                 CH_WAVE_SYNC();
             }
+            CHB_T(tU)
             if (s + 1 < nb) factor_diag(s + 1);
+            CHB_T(tF)
         } else {
             const int ntile = m * (m + 1) / 2;
             for (int t = wave; t < ntile; t += NW - 1) { /* tile t = (ii, jj), jj <= ii, row-major over the triangle; t = 0 is wavefront 0's */
@@ -1119,7 +1134,11 @@ __device__ __forceinline__ bool ba_chol_band(const BAWin &w, double *D, const in
             stage_A(last_of(s + 2), last_of(s + 3));
         }
         chb_barrier();
+        CHB_T(tbB)
     }
+    if ((skip & 32) && tid == 0 && blockIdx.x == 0)
+        printf("[chol band] %d steps, us per step on the chain wavefront: phase A %.2f | barrier A %.2f | update (s+1,s+1) %.2f | factor+inverse %.2f | barrier B %.2f\n",
+               nb, tA * 0.01 / nb, tbA * 0.01 / nb, tU * 0.01 / nb, tF * 0.01 / nb, tbB * 0.01 / nb);
     __syncthreads(); /* (a full one: the L tiles and inverse diagonal tiles written above are read below) */
     const bool ok = bad_flag[0] == 0.0;
     /* backward substitution L^T x = y, row by row from the bottom; row i belongs to wavefront i mod NW */
