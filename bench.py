@@ -206,10 +206,12 @@ def single_stream(n_frames):
         frames, gt, K, _ = sq.make_plane_sequence(5, n_frames)
         frames.tofile(td + "/f.raw")
         gt.astype(np.float64).tofile(td + "/gt.bin")
+        # the child is not part of a profiling session of this process (rocprofv3 preloads its tool through the environment)
+        env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF"))}
         best = None
         for _ in range(2):   # the first run pages the binary and the library in
             p = subprocess.run([exe, str(frames.shape[2]), str(frames.shape[1]), str(n_frames), td + "/f.raw", td + "/gt.bin",
-                                *("%.17g" % v for v in K), td + "/out.bin"], capture_output=True, text=True, timeout=300)
+                                *("%.17g" % v for v in K), td + "/out.bin"], capture_output=True, text=True, timeout=300, env=env)
             if p.returncode != 0:
                 return {"error": "tracking_main exited with %d: %s" % (p.returncode, p.stderr[-200:])}
             j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])

@@ -4001,8 +4001,11 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
             int first = it == 0 ? 1 : 0, solver = s->solver, g = G, sq = seq++, nit = std::min(per_launch, P0.rounds[round] - it);
             double tol2 = s->pcg_tol2;
             int dbg = debug;
-            static const bool no_coop = getenv("ORBSLAM_AMD_BA_NO_COOP") != nullptr; /* diagnostics: rocprofv3 (ROCm 7.2) crashes
-                                                                                          at process exit after a cooperative launch */
+            /* diagnostics: launch teams non-cooperatively.  (Round 2 used this to get profiled runs to exit cleanly and blamed
+               the cooperative launch; round 3 found the cause elsewhere -- a race inside rocprofv3's counter-collection worker
+               when a process exits right after a burst of dispatches, profiles/r03_profiler_exit_hang.md -- and profiles
+               with cooperative launches again.) */
+            static const bool no_coop = getenv("ORBSLAM_AMD_BA_NO_COOP") != nullptr;
             if (G > 1 && !no_coop) {
                 /* a team needs all its workgroups resident at once: cooperative launch (the runtime checks the grid
                    against the device and never runs two cooperative kernels side by side) */
@@ -4232,7 +4235,12 @@ __device__ __forceinline__ double po_chi2(const double *pose, const double *xw, 
  * registers (with a `break` in the column loop the compiler kept A[] in scratch memory: 10 us per solve, two
  * thirds of the whole pose optimisation).  Same operations in the same order as the plain loops. */
 __device__ __forceinline__ bool po_chol6_solve(const double *H, double lambda, const double *b, double *x) {
-    double A[36];
+    /* No f64 square root and no f64 division (six and twenty-seven of them stood here: each expands to a few dozen
+       dependent half-rate instructions, and every one of the 40 iterations of a pose problem waits for this solve): a
+       column is scaled by r = 1 / sqrt(d) from v_rsq_f64 (about 2^-23) and one cubically convergent step
+       r (1 + e / 2 + 3 e^2 / 8), e = 1 - d r^2 (relative error below 2^-60), the pivot is d r, and the substitutions
+       multiply by the same r. */
+    double A[36], rinv[6];
 #pragma unroll
     for (int i = 0; i < 36; i++) A[i] = H[i];
 #pragma unroll
@@ -4247,14 +4255,19 @@ __device__ __forceinline__ bool po_chol6_solve(const double *H, double lambda, c
             ok = false;
             d = 1.0; /* keep going with harmless values; the caller discards the result */
         }
-        d = sqrt(d);
-        A[j * 6 + j] = d;
+        double r = __builtin_amdgcn_rsq(d);
+        {
+            const double e = __builtin_fma(-(d * r), r, 1.0);
+            r = __builtin_fma(r, __builtin_fma(0.375, e, 0.5) * e, r);
+        }
+        rinv[j] = r;
+        A[j * 6 + j] = d * r;
 #pragma unroll
         for (int i = j + 1; i < 6; i++) {
             double v = A[i * 6 + j];
 #pragma unroll
             for (int kk = 0; kk < j; kk++) v -= A[i * 6 + kk] * A[j * 6 + kk];
-            A[i * 6 + j] = v / d;
+            A[i * 6 + j] = v * r;
         }
     }
 #pragma unroll
@@ -4262,14 +4275,14 @@ __device__ __forceinline__ bool po_chol6_solve(const double *H, double lambda, c
         double v = b[i];
 #pragma unroll
         for (int kk = 0; kk < i; kk++) v -= A[i * 6 + kk] * x[kk];
-        x[i] = v / A[i * 6 + i];
+        x[i] = v * rinv[i];
     }
 #pragma unroll
     for (int i = 5; i >= 0; i--) {
         double v = x[i];
 #pragma unroll
         for (int kk = i + 1; kk < 6; kk++) v -= A[kk * 6 + i] * x[kk];
-        x[i] = v / A[i * 6 + i];
+        x[i] = v * rinv[i];
     }
     return ok;
 }
@@ -4399,7 +4412,8 @@ __global__ __launch_bounds__(PO_T) void k_pose_opt(double *pose7_all, const doub
                 scale += 1e-3;
                 rho = (currentChi - tempChi) / scale;
                 if (rho > 0 && isfinite(tempChi)) {
-                    double alpha = 1. - pow((2 * rho - 1), 3);
+                    const double t3 = 2 * rho - 1;
+                    double alpha = 1. - t3 * t3 * t3; /* (pow(t, 3) is a few hundred instructions on the chain of every iteration) */
                     alpha = fmin(alpha, 2. / 3.);
                     lambda *= fmax(1. / 3., alpha);
                     ni = 2;

@@ -779,6 +779,8 @@ struct OrbMatcher {
     uint16_t *d_best = nullptr, *d_second = nullptr;
     uint8_t *d_scratch = nullptr; /* N4 searches: query parameters and result lists, grown on demand */
     size_t cap_scratch = 0;
+    uint8_t *h_n4 = nullptr;      /* pinned mirror of d_scratch (one upload, one download per N4 search) */
+    size_t cap_h_n4 = 0;
     bool profile = false;
     static const int kProfRing = 64;
     hipEvent_t ev[64][3] = {}; /* start, end, between phase 1 (knn) and phase 2 (resolve) */
@@ -837,6 +839,7 @@ extern "C" void orb_matcher_destroy(OrbMatcher *m) {
     (void)hipFree(m->d_best);
     (void)hipFree(m->d_second);
     (void)hipFree(m->d_scratch);
+    if (m->h_n4) (void)hipHostFree(m->h_n4);
     for (int r = 0; r < OrbMatcher::kProfRing; r++)
         for (int i = 0; i < 3; i++)
             if (m->ev[r][i]) (void)hipEventDestroy(m->ev[r][i]);
@@ -1108,6 +1111,15 @@ static int n4_scratch(OrbMatcher *m, size_t bytes) {
     m->cap_scratch = bytes;
     return ORB_OK;
 }
+static int n4_pinned(OrbMatcher *m, size_t bytes) {
+    if (bytes <= m->cap_h_n4) return ORB_OK;
+    if (m->h_n4) MCHK(hipHostFree(m->h_n4));
+    m->h_n4 = nullptr;
+    m->cap_h_n4 = 0;
+    MCHK(hipHostMalloc((void **)&m->h_n4, bytes + bytes / 4));
+    m->cap_h_n4 = bytes + bytes / 4;
+    return ORB_OK;
+}
 static inline int host_hamming(const uint8_t *a, const uint8_t *b) {
     int d = 0;
     for (int k = 0; k < 4; k++) {
@@ -1157,34 +1169,39 @@ extern "C" int orb_search_by_projection(OrbMatcher *m, const OrbFrameView *cur, 
     if (cur->n == 0 || last->n == 0) return ORB_OK;
     MCHK(hipSetDevice(m->device));
     const int nq = last->n, n2 = cur->n, TH_HIGH = 100;
-    /* scratch: flags | xw | pose | scale factors | qxyr | qlvl | lists */
+    /* device scratch: [ inputs: flags | xw | pose | scale factors | cur kps | cur desc | last kps | last desc ]
+                       [ outputs: qxyr | qlvl | candidate lists ]
+       The inputs are packed into ONE pinned block and go up as one copy, the outputs come down as one copy into pinned
+       memory: eight uploads from pageable memory and three downloads into std::vectors (each a blocking bounce through the
+       runtime's staging buffer) were most of the call -- Tracking makes it once or twice per frame (src/Tracking.cpp:344,348) */
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t o_fl = 0, o_xw = al(o_fl + nq), o_pose = al(o_xw + (size_t)nq * 24), o_sf = al(o_pose + 96),
-                 o_q = al(o_sf + (size_t)nlevels * 4), o_lv = al(o_q + (size_t)nq * 12), o_out = al(o_lv + (size_t)nq * 8),
-                 total = al(o_out + (size_t)nq * QK_TOP * 8);
+                 o_k2 = al(o_sf + (size_t)nlevels * 4), o_d2 = al(o_k2 + (size_t)n2 * sizeof(OrbKeyPoint)),
+                 o_k1 = al(o_d2 + (size_t)n2 * 32), o_d1 = al(o_k1 + (size_t)nq * sizeof(OrbKeyPoint)), in_bytes = al(o_d1 + (size_t)nq * 32),
+                 o_q = in_bytes, o_lv = al(o_q + (size_t)nq * 12), o_out = al(o_lv + (size_t)nq * 8),
+                 total = al(o_out + (size_t)nq * QK_TOP * 8), out_bytes = total - o_q;
     int rc;
     if ((rc = n4_scratch(m, total))) return rc;
-    double pose[12];
-    memcpy(pose, Rcw9, 72);
-    memcpy(pose + 9, tcw3, 24);
-    uint8_t *S = m->d_scratch;
-    MCHK(hipMemcpyAsync(S + o_fl, last_flags, nq, hipMemcpyHostToDevice, m->stream));
-    MCHK(hipMemcpyAsync(S + o_xw, last_xw, (size_t)nq * 24, hipMemcpyHostToDevice, m->stream));
-    MCHK(hipMemcpyAsync(S + o_pose, pose, 96, hipMemcpyHostToDevice, m->stream));
-    MCHK(hipMemcpyAsync(S + o_sf, scale_factors, (size_t)nlevels * 4, hipMemcpyHostToDevice, m->stream));
-    /* frame slot 0 = the current frame (candidates), slot 1 = the last frame (queries) */
-    MCHK(hipMemcpyAsync(m->d_kps, cur->kps, (size_t)n2 * sizeof(OrbKeyPoint), hipMemcpyHostToDevice, m->stream));
-    MCHK(hipMemcpyAsync(m->d_desc, cur->desc, (size_t)n2 * 32, hipMemcpyHostToDevice, m->stream));
-    MCHK(hipMemcpyAsync(m->d_kps + m->max_kp, last->kps, (size_t)nq * sizeof(OrbKeyPoint), hipMemcpyHostToDevice, m->stream));
-    MCHK(hipMemcpyAsync(m->d_desc + (size_t)m->max_kp * 32, last->desc, (size_t)nq * 32, hipMemcpyHostToDevice, m->stream));
-    hipLaunchKernelGGL(k_project_queries, dim3((nq + 255) / 256), dim3(256), 0, m->stream, m->d_kps + m->max_kp, S + o_fl,
+    if ((rc = n4_pinned(m, total))) return rc;
+    uint8_t *S = m->d_scratch, *P = m->h_n4;
+    memcpy(P + o_fl, last_flags, nq);
+    memcpy(P + o_xw, last_xw, (size_t)nq * 24);
+    memcpy(P + o_pose, Rcw9, 72);
+    memcpy(P + o_pose + 72, tcw3, 24);
+    memcpy(P + o_sf, scale_factors, (size_t)nlevels * 4);
+    memcpy(P + o_k2, cur->kps, (size_t)n2 * sizeof(OrbKeyPoint));
+    memcpy(P + o_d2, cur->desc, (size_t)n2 * 32);
+    memcpy(P + o_k1, last->kps, (size_t)nq * sizeof(OrbKeyPoint));
+    memcpy(P + o_d1, last->desc, (size_t)nq * 32);
+    MCHK(hipMemcpyAsync(S, P, in_bytes, hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(k_project_queries, dim3((nq + 255) / 256), dim3(256), 0, m->stream, (const OrbKeyPoint *)(S + o_k1), S + o_fl,
                        (const double *)(S + o_xw), nq, (const double *)(S + o_pose), fx, fy, cx, cy, cur->min_x, cur->max_x,
                        cur->min_y, cur->max_y, (const float *)(S + o_sf), nlevels, th, (float *)(S + o_q), (int32_t *)(S + o_lv));
     QueryArgs A{};
-    A.kps2 = m->d_kps;
-    A.desc2 = m->d_desc;
+    A.kps2 = (const OrbKeyPoint *)(S + o_k2);
+    A.desc2 = S + o_d2;
     A.n2 = n2;
-    A.qdesc = m->d_desc + (size_t)m->max_kp * 32;
+    A.qdesc = S + o_d1;
     A.qxyr = (const float *)(S + o_q);
     A.qlvl = (const int32_t *)(S + o_lv);
     A.nq = nq;
@@ -1193,13 +1210,11 @@ extern "C" int orb_search_by_projection(OrbMatcher *m, const OrbFrameView *cur, 
     A.out = (unsigned long long *)(S + o_out);
     hipLaunchKernelGGL(k_query_topk, dim3((nq + 256 / QK_SLICES - 1) / (256 / QK_SLICES)), dim3(256), 0, m->stream, A);
     MCHK(hipGetLastError());
-    std::vector<unsigned long long> lists((size_t)nq * QK_TOP);
-    std::vector<float> qxyr((size_t)nq * 3);
-    std::vector<int32_t> qlvl((size_t)nq * 2);
-    MCHK(hipMemcpyAsync(lists.data(), S + o_out, lists.size() * 8, hipMemcpyDeviceToHost, m->stream));
-    MCHK(hipMemcpyAsync(qxyr.data(), S + o_q, qxyr.size() * 4, hipMemcpyDeviceToHost, m->stream));
-    MCHK(hipMemcpyAsync(qlvl.data(), S + o_lv, qlvl.size() * 4, hipMemcpyDeviceToHost, m->stream));
+    MCHK(hipMemcpyAsync(P + o_q, S + o_q, out_bytes, hipMemcpyDeviceToHost, m->stream));
     MCHK(hipStreamSynchronize(m->stream));
+    const unsigned long long *lists = (const unsigned long long *)(P + o_out);
+    const float *qxyr = (const float *)(P + o_q);
+    const int32_t *qlvl = (const int32_t *)(P + o_lv);
     /* the sequential walk: feature i takes the closest candidate that is still free */
     const float invW = (float)GRID_COLS / (cur->max_x - cur->min_x), invH = (float)GRID_ROWS / (cur->max_y - cur->min_y);
     std::vector<std::pair<int, int>> acc; /* (rotation bin, feature) of every acceptance */

@@ -18,6 +18,12 @@ def rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
+# Tolerance carve-outs taken during a sweep, COUNTED (VERDICT r2 #1c): a window accepted although (a) its iteration count
+# differs from the oracle's (both converged to the same cost: the sign of the gain ratio at the minimum is rounding noise)
+# or (b) it misses 1e-5 but stays within a multiple of the oracle's own sensitivity to a 1e-13 perturbation of its input
+CARVEOUTS = {"iterations_differ_same_cost": 0, "unstable_problem_within_own_sensitivity": 0, "windows_checked": 0}
+
+
 def run(n_cfg=24, seed=3):
     rng = np.random.default_rng(seed)
     opt = oa.Optimizer(max_cams=128, max_points=8192, max_obs=80000, max_batch=4)
@@ -48,6 +54,9 @@ def run(n_cfg=24, seed=3):
               rel(got["points"], ref["points"]) < 1e-5 and rel(got["poses"][:, 4:], ref["poses"][:, 4:]) < 1e-5 and
               abs(got["chi2_final"] - ref["chi2_final"]) <= 1e-6 * max(ref["chi2_final"], 1e-30))
         bad += 0 if ok else 1
+        CARVEOUTS["windows_checked"] += 1
+        if ok and got["iterations"] != ref["iterations"]:
+            CARVEOUTS["iterations_differ_same_cost"] += 1
         if not ok:
             print("   iterations %d/%d  lin_solves %d/%d  outlier flags differ at %d edges  rel(poses t) %.1e  chi2 %.9e / %.9e" % (
                 got["iterations"], ref["iterations"], got["lin_solves"], ref["lin_solves"],
@@ -73,7 +82,7 @@ def run(n_cfg=24, seed=3):
                                                                              int(np.count_nonzero(go != ro)), np.abs(gp - rp).max()))
     print("FUZZ-POSE %s: %d mismatches in %d problems" % ("FAILED" if pbad else "OK", pbad, n_cfg))
     bad += pbad
-    print("FUZZ-BA %s: %d mismatches in %d configs" % ("FAILED" if bad else "OK", bad, n_cfg))
+    print("FUZZ-BA %s: %d mismatches in %d configs; carve-outs so far: %s" % ("FAILED" if bad else "OK", bad, n_cfg, CARVEOUTS))
     return 1 if bad else 0
 
 
@@ -126,7 +135,11 @@ def run_batches(n_batches=2, seed=11, sample=3):
                 if own > 2e-7 and rel(g["points"], ref["points"]) < 50 * own:
                     print("   batch %d window %d: unstable problem (oracle vs itself at 1e-13: %.1e, device vs oracle: %.1e): accepted" % (
                         b, i, own, rel(g["points"], ref["points"])))
+                    CARVEOUTS["unstable_problem_within_own_sensitivity"] += 1
                     ok = True
+            CARVEOUTS["windows_checked"] += 1
+            if ok and g["iterations"] != ref["iterations"]:
+                CARVEOUTS["iterations_differ_same_cost"] += 1
             if not ok:
                 nb += 1
                 print("   batch %d window %d: cams %d points %d its %d/%d solves %d/%d flags differ %d rel(points) %.1e chi2 %.9e / %.9e" % (
@@ -135,7 +148,7 @@ def run_batches(n_batches=2, seed=11, sample=3):
         print("batch %d: %d windows, rounds %s robust %d, %s: %d mismatches in %d checked" % (
             b, nwin, rounds, robust, "phase kernels" if team == 0 else "fused kernel (team %d)" % team, nb, len(range(0, nwin, sample))), flush=True)
         bad += nb
-    print("FUZZ-BA-BATCH %s: %d mismatches" % ("FAILED" if bad else "OK", bad))
+    print("FUZZ-BA-BATCH %s: %d mismatches; carve-outs so far: %s" % ("FAILED" if bad else "OK", bad, CARVEOUTS))
     return 1 if bad else 0
 
 

@@ -125,6 +125,9 @@ def test_ba_global_reference_graph_outliers_20_iterations(opt, oracle):
     inl = np.abs(r_ref).max(axis=1) < 20.0
     own_r = max(np.abs(r_alt - r_ref)[inl].max(), REL * np.abs(r_ref[inl]).max())
     assert np.abs(r_got - r_ref)[inl].max() < K * own_r
+    import warnings   # a tolerance wider than 1e-5 is a carve-out: counted and shown (VERDICT r2 #1c)
+    warnings.warn("BA carve-out (K x own sensitivity, 1 window): device vs oracle rel(points) %.2e, oracle vs itself at 1e-13 %.2e, "
+                  "bound %.2e" % (_rel(got["points"], ref["points"]), _rel(alt["points"], ref["points"]), K * own))
 
 
 def test_ba_degenerate_windows(opt, oracle):

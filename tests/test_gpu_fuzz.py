@@ -23,10 +23,21 @@ def test_front_end_fuzz(seed, wild):
     assert _load("fuzz_parity").run(6, seed, wild) == 0
 
 
+def _report_carveouts(mod):
+    """the tolerance carve-outs a sweep took are part of its result: counted, and shown in the warnings summary of the run"""
+    import warnings
+    warnings.warn("BA fuzz carve-outs (tests/fuzz_ba.py): %s" % dict(mod.CARVEOUTS))
+
+
 def test_ba_fuzz():
-    assert _load("fuzz_ba").run(8, 20263) == 0
+    mod = _load("fuzz_ba")
+    assert mod.run(8, 20263) == 0
+    _report_carveouts(mod)
 
 
 def test_ba_batch_fuzz():
     """a batch of 129+ random windows (the phase-kernel path), a third of them against the oracle"""
-    assert _load("fuzz_ba").run_batches(1, 20264, 3) == 0
+    mod = _load("fuzz_ba")
+    assert mod.run_batches(1, 20264, 3) == 0
+    _report_carveouts(mod)
+    assert mod.CARVEOUTS["unstable_problem_within_own_sensitivity"] <= 1   # (one window in ~4000 of the long sweeps; none expected in this slice)

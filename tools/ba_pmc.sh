@@ -1,7 +1,9 @@
 #!/bin/bash
 # PMC passes over the BA phase kernels (one 256-window batch, two solves): tools/ba_pmc.sh <tag>
 # separate rocprofv3 runs per counter group (kernel-trace only beside --pmc), summarised by tools/collect_sq.py.
-# rocprofv3 (ROCm 7.2) may hang at process exit after its output is written: every pass runs under a short timeout.
+# A process that exits right after a burst of dispatches races rocprofv3's counter-collection worker (crash or hang inside
+# the profiler, profiles/r03_profiler_exit_hang.md); orbslam_in_practice_amd/_lib.py drains 2 s at exit under rocprofv3, the
+# timeout below is only a bound.
 tag=${1:-ba}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

@@ -19,7 +19,7 @@ import sys
 
 KERNELS = ["k_fast_cells_wave", "k_quadtree", "k_blur", "k_describe", "k_match_knn", "k_match_init", "k_resize", "k_copy_level0",
            "k_ba_iteration", "k_ba_classify", "k_pose_opt", "k_pyramid", "k_ba_ph_chi2", "k_ba_ph_hll", "k_ba_ph_hpp", "k_ba_ph_prep",
-           "k_ba_ph_dinv", "k_ba_ph_schur2", "k_ba_ph_chol", "k_ba_ph_decide", "k_ba_ph_round", "k_ba_ph_backsub", "k_ba_ph_trial", "k_ba_ph_accept", "k_ba_ph_finish"]
+           "k_ba_ph_dinv", "k_ba_ph_schur2", "k_ba_ph_chol", "k_ba_ph_chol_band", "k_ba_ph_fillplan", "k_ba_ph_decide", "k_ba_ph_round", "k_ba_ph_backsub", "k_ba_ph_trial", "k_ba_ph_accept", "k_ba_ph_finish"]
 
 
 def main():
