@@ -833,27 +833,30 @@ __global__ __launch_bounds__(256) void k_ba_ph_fillplan(BABufs bufs) {
     if (w.fplan < 0) return;
     int32_t *plan = (int32_t *)(bufs.D + w.fplan);
     const int n = w.Ncf * 6, np = (n + 15) & ~15, nb = np >> 4, M = w.ch_pm >> 4;
-    const int32_t *efirst = I + w.ch_first;
     for (int i = threadIdx.x; i <= nb; i += 256) cnt[i] = 0;
     __syncthreads();
+    /* one thread per BLOCK of the lower triangle (its four index loads form one round trip, shared by its 36 entries);
+       pass 0 counts the entries per tile row, pass 1 writes them behind the scanned starts */
     for (int pass = 0; pass < 2; pass++) {
-        for (int it = threadIdx.x; it < w.nnzb * 36; it += 256) {
-            const int bk = it / 36, e = it - bk * 36;
+        for (int bk = threadIdx.x; bk < w.nnzb; bk += 256) {
             const int c = I[w.blk_rowid + bk], j = I[w.blk_col + bk];
             if (j > c) continue;
-            const int rr = e / 6, cc = e - rr * 6;
-            const int row = 6 * c + cc, col = 6 * j + rr; /* lower-triangle entry = upper block (j, c) entry [rr][cc] */
-            if (col > row) continue;
-            const int ti = row >> 4, tj = col >> 4;
-            if (pass == 0) {
-                atomicAdd(&cnt[ti], 1);
-            } else {
-                const int pos = atomicAdd(&cnt[ti], 1);
-                const int mi = I[w.blk_mirror + bk];
-                const int d = ti - tj, slot = chb_base(M, d) + tj % chb_ring(M, d);
-                (void)efirst;
-                plan[chb_ent0(nb) + 2 * pos] = (mi * 36 + e) | ((I[w.blk_touch + mi] & 2) ? (int)0x80000000 : 0);
-                plan[chb_ent0(nb) + 2 * pos + 1] = slot * CHB_TILE + (row & 15) * CH_LD + (col & 15);
+            const int mi = I[w.blk_mirror + bk];
+            const int two = (I[w.blk_touch + mi] & 2) ? (int)0x80000000 : 0;
+#pragma unroll 6
+            for (int e = 0; e < 36; e++) {
+                const int rr = e / 6, cc = e - rr * 6;
+                const int row = 6 * c + cc, col = 6 * j + rr; /* lower-triangle entry = upper block (j, c) entry [rr][cc] */
+                if (col > row) continue;
+                const int ti = row >> 4, tj = col >> 4;
+                if (pass == 0) {
+                    atomicAdd(&cnt[ti], 1);
+                } else {
+                    const int pos = atomicAdd(&cnt[ti], 1);
+                    const int d = ti - tj, slot = chb_base(M, d) + tj % chb_ring(M, d);
+                    plan[chb_ent0(nb) + 2 * pos] = (mi * 36 + e) | two;
+                    plan[chb_ent0(nb) + 2 * pos + 1] = slot * CHB_TILE + (row & 15) * CH_LD + (col & 15);
+                }
             }
         }
         __syncthreads();
@@ -1192,6 +1195,13 @@ __device__ __noinline__ bool ba_chol_band_fused4(const BAWin &w, double *D, cons
 }
 __device__ __noinline__ bool ba_chol_band_fused8(const BAWin &w, double *D, const int32_t *I, int n, double *dyn, double *bad_flag) {
     return ba_chol_band<BA_T, false, 8>(w, D, I, n, dyn, bad_flag);
+}
+/* ... and for k_ba_ph_finish (the two-part Schur accumulators S + S2, g + g2) */
+__device__ __noinline__ bool ba_chol_band_two4(const BAWin &w, double *D, const int32_t *I, int n, double *dyn, double *bad_flag) {
+    return ba_chol_band<BA_T, true, 4>(w, D, I, n, dyn, bad_flag);
+}
+__device__ __noinline__ bool ba_chol_band_two8(const BAWin &w, double *D, const int32_t *I, int n, double *dyn, double *bad_flag) {
+    return ba_chol_band<BA_T, true, 8>(w, D, I, n, dyn, bad_flag);
 }
 
 /* Schur complement, batch path (one workgroup per window).
@@ -2273,7 +2283,7 @@ struct BARed {
     double red[BA_W];
     double bc[8];
 };
-#define BA_PH_SPARE 2
+#define BA_PH_SPARE 3 /* trials enqueued per round beyond its iterations (2 -> 3: 16.56 -> 16.16 ms per round of 256 windows; 4: 16.18) */
 /* phase kernels from this many windows on: 6, or 4 when no window has BA_SPLIT_BIG_EDGES edges (ba_stage has the
    measurements) */
 #define BA_SPLIT_MIN_WINDOWS 6
@@ -2329,13 +2339,18 @@ template <class SH> __device__ __forceinline__ void ba_ph_dinv(const BAWin &w, d
         ba_phase_dinv<false>(w, D, I, lambda, threadIdx.x, BA_T);
     }
 }
-__device__ __forceinline__ void ba_ph_chol(const BAWin &w, double *D, const int32_t *I, double *dyn, double *bad_flag) {
+__device__ __forceinline__ void ba_ph_chol(const BAWin &w, double *D, const int32_t *I, double *dyn, double *bad_flag, bool band = false) {
     double *st = D + w.st;
     const int n = w.Ncf * 6;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    ba_chol_assemble<true>(w, D, I, n, threadIdx.x, BA_T, wave, BA_W, [&] { __syncthreads(); });
-    __syncthreads();
-    const bool ok2 = ba_chol_solve<true>(w, D, I, n, dyn, bad_flag, 0);
+    bool ok2;
+    if (band) { /* the batch runs the band Cholesky: the same solver (and the same arithmetic) for the trials finished here */
+        ok2 = (w.ch_pm >> 4) <= 4 ? ba_chol_band_two4(w, D, I, n, dyn, bad_flag) : ba_chol_band_two8(w, D, I, n, dyn, bad_flag);
+    } else {
+        ba_chol_assemble<true>(w, D, I, n, threadIdx.x, BA_T, wave, BA_W, [&] { __syncthreads(); });
+        __syncthreads();
+        ok2 = ba_chol_solve<true>(w, D, I, n, dyn, bad_flag, 0);
+    }
     if (threadIdx.x == 0) {
         st[ST_OK2] = ok2 ? 1.0 : 0.0;
         st[ST_SOLVES] += 1.0;
@@ -2873,7 +2888,7 @@ __global__ __launch_bounds__(BA_PH_T) void k_ba_ph_accept(BABufs bufs, int trial
     ba_phase_accept(w, D, blockIdx.y * BA_PH_T + threadIdx.x, gridDim.y * BA_PH_T);
 }
 /* whatever is left of the round, in one workgroup per window (normally nothing: every window is at ST_PH == 2) */
-__global__ __launch_bounds__(BA_T) void k_ba_ph_finish(BABufs bufs) {
+__global__ __launch_bounds__(BA_T) void k_ba_ph_finish(BABufs bufs, int band) {
     extern __shared__ __attribute__((aligned(16))) double ba_dyn[];
     __shared__ BARed s;
     const BAWin &w = bufs.wins[blockIdx.x];
@@ -2907,7 +2922,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_ph_finish(BABufs bufs) {
             ba_g_lists(w, D, I, wv, BA_W);
         }
         __syncthreads();
-        ba_ph_chol(w, D, I, ba_dyn, &s.bc[0]);
+        ba_ph_chol(w, D, I, ba_dyn, &s.bc[0], band != 0);
         __syncthreads();
         ba_ph_update(w, D, I, B, s);
         __syncthreads();
@@ -3862,7 +3877,7 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
         static const int band_env = getenv("ORBSLAM_AMD_BA_CHOL_BAND") ? atoi(getenv("ORBSLAM_AMD_BA_CHOL_BAND")) : 1;
         static const int band_nt_env = getenv("ORBSLAM_AMD_BA_CHOL_NT") ? atoi(getenv("ORBSLAM_AMD_BA_CHOL_NT")) : 0;
         static const int band_skip = getenv("ORBSLAM_AMD_BA_CHOL_SKIP") ? atoi(getenv("ORBSLAM_AMD_BA_CHOL_SKIP")) : 0; /* timing experiments (results invalid) */
-        size_t band_doubles = 0;
+        size_t band_doubles = 0, fin_doubles = std::max<size_t>(chol_doubles, 2 * (size_t)BA_CHUNK_DOUBLES);
         int band_maxm = 0;
         bool band = band_env != 0;
         for (int i = 0; i < nwin && band; i++) {
@@ -3880,8 +3895,8 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
         if (band) {
             static PerDeviceLdsLimit lim_band[4];
             BCHK(lim_band[(band_nt == 256 ? 0 : 2) + (band_maxm <= 4 ? 0 : 1)].ensure(band_fn, band_doubles * 8));
+            fin_doubles = std::max(fin_doubles, band_doubles);
         }
-        const size_t fin_doubles = std::max<size_t>(chol_doubles, 2 * (size_t)BA_CHUNK_DOUBLES);
         BCHK(lim_fin.ensure((const void *)k_ba_ph_finish, fin_doubles * 8));
         static const bool phase_prof = getenv("ORBSLAM_AMD_BA_PHASE_PROF") != nullptr; /* diagnostics: serialises the phases */
         double phase_ms[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -3970,7 +3985,7 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
                     return rc;
             }
             if (nit > 0)
-                if ((rc = timed(9, [&] { hipLaunchKernelGGL(k_ba_ph_finish, dim3(nwin), dim3(BA_T), fin_doubles * 8, ks, bufs); }))) return rc;
+                if ((rc = timed(9, [&] { hipLaunchKernelGGL(k_ba_ph_finish, dim3(nwin), dim3(BA_T), fin_doubles * 8, ks, bufs, band ? 1 : 0); }))) return rc;
             if (s->profiling) BCHK(hipEventRecord(J.prof_ev[2 * J.prof_launches + 1], ks));
             J.prof_launches++;
             if (round + 1 < P0.n_rounds) {
@@ -4001,10 +4016,11 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
             int first = it == 0 ? 1 : 0, solver = s->solver, g = G, sq = seq++, nit = std::min(per_launch, P0.rounds[round] - it);
             double tol2 = s->pcg_tol2;
             int dbg = debug;
-            /* diagnostics: launch teams non-cooperatively.  (Round 2 used this to get profiled runs to exit cleanly and blamed
-               the cooperative launch; round 3 found the cause elsewhere -- a race inside rocprofv3's counter-collection worker
-               when a process exits right after a burst of dispatches, profiles/r03_profiler_exit_hang.md -- and profiles
-               with cooperative launches again.) */
+            /* profiling sessions: launch teams non-cooperatively.  Under rocprofv3 a process that made a cooperative launch
+               segfaults at exit inside the HIP runtime's code-object unregistration (failure A of
+               profiles/r03_profiler_exit_hang.md).  It is NOT the cause of the profiled phase-kernel runs that hung in
+               round 2 -- those made no cooperative launch; that was a race inside the profiler's counter-collection worker
+               at exit (failure B, same file), handled by draining before exit. */
             static const bool no_coop = getenv("ORBSLAM_AMD_BA_NO_COOP") != nullptr;
             if (G > 1 && !no_coop) {
                 /* a team needs all its workgroups resident at once: cooperative launch (the runtime checks the grid

@@ -12,7 +12,7 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GR
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE"; do
   d=$R/gpurun_out/pmc_${tag}_$(echo $grp | cut -d' ' -f1)
   rm -rf $d
-  timeout -k 5 75 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $d -- python3 $R/tools/ba_probe.py 32 > $d.log 2>&1
+  timeout -k 5 150 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $d -- python3 $R/tools/ba_probe.py 32 > $d.log 2>&1
   echo "pass $(echo $grp | cut -d' ' -f1): rc $? $(ls $d/*/*counter_collection.csv 2>/dev/null | wc -l) csv"
 done
 python3 $R/tools/collect_sq.py $R/gpurun_out/pmc_${tag}.json $R/gpurun_out/pmc_${tag}_*/

@@ -1,8 +1,11 @@
 #!/bin/bash
 # the round's profile set for the default bench line: tools/profile_bench.sh <tag>
 #   kernel trace + stats, FETCH_SIZE and WRITE_SIZE passes (separate runs), summaries under gpurun_out/<tag>_*
-# (Exit-time crashes / hangs of profiled runs were a race inside rocprofv3 at process exit, not the cooperative launch:
-# profiles/r03_profiler_exit_hang.md.  _lib.py drains 2 s at exit under rocprofv3; the timeouts are bounds.)
+# Two different exit-time failures of profiled runs exist (profiles/r03_profiler_exit_hang.md): (A) after a COOPERATIVE
+# launch the process segfaults inside libamdhip64's __hipUnregisterFatBinary at exit under rocprofv3 -- teams are launched
+# non-cooperatively here; (B) a --pmc pass races its own worker thread when the process exits right after a burst of
+# dispatches -- orbslam_in_practice_amd/_lib.py drains 2 s at exit under rocprofv3.  The timeouts are bounds, not fixes.
+export ORBSLAM_AMD_BA_NO_COOP=1
 tag=${1:-prof}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
