@@ -3815,7 +3815,7 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
         if (J.team == 1 && J.wins[i].nchunks > 0) dyn_doubles = std::max(dyn_doubles, (int)BA_CHUNK_DOUBLES);
     /* the band Cholesky (LDS-resident window, ba_chol_band) inside the fused kernel: when every window with a dense matrix has
        a fill plan and a narrow band; its window must fit beside the static LDS (ORBSLAM_AMD_BA_CHOL_BAND=0: round 2's solver) */
-    static const int fused_band_env = getenv("ORBSLAM_AMD_BA_CHOL_BAND") ? atoi(getenv("ORBSLAM_AMD_BA_CHOL_BAND")) : 1;
+    const int fused_band_env = getenv("ORBSLAM_AMD_BA_CHOL_BAND") ? atoi(getenv("ORBSLAM_AMD_BA_CHOL_BAND")) : 1;
     int fused_band = s->solver == 1 && fused_band_env != 0 ? 1 : 0;
     {
         size_t need = 0;
@@ -3874,8 +3874,9 @@ static int ba_enqueue(BASolver *s, BAJob &J) {
         /* band Cholesky with the LDS-resident window (ba_chol_band) when every window's band is narrow enough; 256 threads
            per window -- two windows per CU -- once the batch can fill the device that way.  ORBSLAM_AMD_BA_CHOL_BAND=0:
            the round-2 kernel; ORBSLAM_AMD_BA_CHOL_NT=256 / 512 forces the workgroup size (tests, measurements). */
-        static const int band_env = getenv("ORBSLAM_AMD_BA_CHOL_BAND") ? atoi(getenv("ORBSLAM_AMD_BA_CHOL_BAND")) : 1;
-        static const int band_nt_env = getenv("ORBSLAM_AMD_BA_CHOL_NT") ? atoi(getenv("ORBSLAM_AMD_BA_CHOL_NT")) : 0;
+        /* (read per call, not cached: the tests switch them inside one process) */
+        const int band_env = getenv("ORBSLAM_AMD_BA_CHOL_BAND") ? atoi(getenv("ORBSLAM_AMD_BA_CHOL_BAND")) : 1;
+        const int band_nt_env = getenv("ORBSLAM_AMD_BA_CHOL_NT") ? atoi(getenv("ORBSLAM_AMD_BA_CHOL_NT")) : 0;
         static const int band_skip = getenv("ORBSLAM_AMD_BA_CHOL_SKIP") ? atoi(getenv("ORBSLAM_AMD_BA_CHOL_SKIP")) : 0; /* timing experiments (results invalid) */
         size_t band_doubles = 0, fin_doubles = std::max<size_t>(chol_doubles, 2 * (size_t)BA_CHUNK_DOUBLES);
         int band_maxm = 0;

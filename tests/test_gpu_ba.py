@@ -538,3 +538,40 @@ def test_ba_bench_launch_shape_every_window_vs_oracle(oracle, nc, npt, nwin):
         _check_estimates(b[nwin - 1 - i], refs[i])
         for k in ("points", "poses", "outlier"):
             assert np.array_equal(a[i][k], got[i][k]) and np.array_equal(b[nwin - 1 - i][k], got[i][k])
+
+
+@pytest.mark.parametrize("variant", ["nt256", "nt512", "round2_solver"])
+def test_ba_cholesky_variants_agree_with_the_oracle(oracle, monkeypatch, variant):
+    """the reduced camera system has three solvers on the phase-kernel path -- the band Cholesky with the LDS-resident
+    window at 256 threads per window (two windows per CU: batches that fill the device twice) and at 512, and round 2's
+    blocked Cholesky on the dense matrix in memory (ORBSLAM_AMD_BA_CHOL_BAND=0, also what a band wider than 8 tile rows
+    falls back to) -- each held to the oracle at 1e-5 on narrow bands (M = 4: short tracks), wider ones (long tracks: the
+    MAXM = 8 instance) and a shuffled camera order (an irregular envelope, beyond the band kernel: the fallback)"""
+    import orbslam_in_practice_amd as oa
+    from orbslam_in_practice_amd import synth
+    if variant == "round2_solver":
+        monkeypatch.setenv("ORBSLAM_AMD_BA_CHOL_BAND", "0")
+    else:
+        monkeypatch.setenv("ORBSLAM_AMD_BA_CHOL_NT", variant[2:])
+    ws = []
+    for i in range(3):
+        w = synth.make_ba_window(8800 + i, 40, 900)
+        w["fixed"][:1 + i] = 1
+        ws.append(w)
+    for i, track in enumerate((10, 14, 18)):
+        ws.append(synth.make_ba_window_long_tracks(8850 + i, 24, 500, track))
+    rng = np.random.default_rng(5)
+    w = synth.make_ba_window(8890, 30, 700)
+    perm = rng.permutation(30)
+    inv = np.empty(30, np.int64)
+    inv[perm] = np.arange(30)
+    w["poses"], w["fixed"] = w["poses"][perm].copy(), w["fixed"][perm].copy()
+    w["cam_idx"] = inv[w["cam_idx"]].astype(np.int32)
+    ws.append(w)
+    o = oa.Optimizer(max_cams=40, max_points=900, max_obs=20000, max_batch=len(ws))
+    o.set_profiling(True)
+    got = o.solve_batch(ws, (5, 10))
+    assert o.iteration_ms()[2] == 0          # phase kernels
+    o.close()
+    for w, g in zip(ws, got):
+        _check_estimates(g, oracle.ba_solve(w, rounds=(5, 10)), converged_ok=True)
