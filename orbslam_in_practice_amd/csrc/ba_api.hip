@@ -3409,6 +3409,8 @@ static int stage_problem(const BAProblem *p, std::vector<double> &hO, std::vecto
         std::vector<int> upper;
         for (int i = 0; i < nnzb; i++)
             if (bmirror[i] >= i) upper.push_back(i);
+        /* (row-major order stays: sorting the blocks by list length, heaviest first, was measured -- one window 7.6 -> 8.3 ms of
+           kernel time: neighbouring blocks share a camera's W records, and that locality is worth more than the balance) */
         w.nub = (int)upper.size();
         w.blk_upper = putI(upper);
     }
