@@ -164,8 +164,10 @@ int orb_features_in_area(OrbMatcher *m, const OrbFrameView *f, const float *quer
  * (src/Tracking.cpp:298,344,348): there is no reference behaviour to be identical to.  These entry points implement
  * upstream ORB-SLAM2's monocular semantics on the reference's data model (oracle/match_oracle.cpp states them line
  * by line): PARITY UNPINNED by construction.  The candidate scan (projection, window / level filter, Hamming
- * distances, the closest candidates per feature) runs on the device, the sequential walk over the features (a
- * feature taken by an earlier one is closed to later ones) and the rotation histogram on the host.  Host pointers.
+ * distances, the closest candidates per feature) runs on the device; for these HOST-POINTER entry points the sequential walk
+ * over the features (a feature taken by an earlier one is closed to later ones) and the rotation histogram run on the host
+ * (10-20 us there; the device walk of orb_search_by_projection_device needs ~70 single-wavefront rounds, and the lists are
+ * coming back with the same copy anyway).  ORBSLAM_AMD_N4_DEVICE_WALK=1 runs the device walk here too (tests).
  *
  * orb_search_by_projection: last_flags[n_last]: bit0 = the feature holds a map point and is not an outlier, bit1 = that
  * map point has observations; last_xw[n_last*3] world positions (read where bit0 is set); Rcw9 / tcw3 the current
@@ -176,6 +178,19 @@ int orb_search_by_projection(OrbMatcher *m, const OrbFrameView *cur, const OrbFr
                              const double *last_xw, const double *Rcw9, const double *tcw3, double fx, double fy, double cx,
                              double cy, const float *scale_factors, int nlevels, uint8_t *cur_taken, float th,
                              int check_orientation, int32_t *cur_match, int32_t *n_matches);
+/* The same search on DEVICE-RESIDENT frames: feature slabs as orb_extract_batch_device left them (d_cur_kps / d_cur_desc /
+ * n_cur of the current frame, d_last_* of the last one), the last frame's flags and world positions, the in/out taken
+ * flags and the results all in device memory; Rcw9 / tcw3 / scale_factors are host arrays read before the call returns.
+ * Projection, candidate scan, the sequential walk (speculative rounds on one wavefront, k_n4_walk) and the rotation
+ * histogram run as three kernels on `stream` (NULL = the matcher's): no copy, no synchronisation.  Identical results to
+ * orb_search_by_projection.  ORB_E_CAPACITY beyond ~8000 features per frame (the walk keeps its state in LDS).
+ * One search in flight per matcher handle (its scratch holds the candidate lists). */
+int orb_search_by_projection_device(OrbMatcher *m, const OrbKeyPoint *d_cur_kps, const uint8_t *d_cur_desc, int n_cur,
+                                    const OrbKeyPoint *d_last_kps, const uint8_t *d_last_desc, int n_last,
+                                    const uint8_t *d_last_flags, const double *d_last_xw, const double *Rcw9, const double *tcw3,
+                                    double fx, double fy, double cx, double cy, const float *scale_factors, int nlevels,
+                                    float min_x, float max_x, float min_y, float max_y, uint8_t *d_cur_taken, float th,
+                                    int check_orientation, int32_t *d_cur_match, int32_t *d_n_matches, void *stream);
 /* orb_search_by_bow: the reference has no vocabulary (ComputeBoW is empty), i.e. one node holding every feature: for every
  * keyframe feature with kf_valid[i] != 0, in index order, best and second best distance over the frame features not
  * matched yet; accepted if best <= TH_LOW (50) and best < nnratio * second.  f_match[n_f] out: keyframe feature or -1. */

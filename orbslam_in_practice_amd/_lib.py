@@ -61,7 +61,7 @@ EXPORTS = [
     "orb_set_profiling", "orb_get_stage_ms", "orb_matcher_set_profiling", "orb_matcher_get_ms", "orb_matcher_get_stage_ms", "orb_features_in_area",
     "orb_descriptor_distance", "orb_compute_three_maxima", "orb_matcher_create", "orb_matcher_destroy",
     "orb_matcher_stream", "orb_matcher_synchronize", "orb_hamming_knn2", "orb_match_init",
-    "orb_match_batch_device", "orb_search_by_projection", "orb_search_by_bow", "ba_create", "ba_destroy", "ba_solve", "ba_solve_batch", "ba_submit_batch", "ba_wait", "ba_set_profiling", "ba_get_iteration_ms",
+    "orb_match_batch_device", "orb_search_by_projection", "orb_search_by_projection_device", "orb_search_by_bow", "ba_create", "ba_destroy", "ba_solve", "ba_solve_batch", "ba_submit_batch", "ba_wait", "ba_set_profiling", "ba_get_iteration_ms",
     "ba_pose_optimization", "ba_pose_optimization_batch",
 ]
 
@@ -74,6 +74,30 @@ def build(verbose=False):
     subprocess.check_call(cmd)
 
 
+def _one_hip_runtime():
+    """A PyTorch-ROCm wheel ships its own libamdhip64.so.  If this package's library is loaded first it pulls in the
+    system runtime (/opt/rocm), a later `import torch` loads the wheel's copy beside it, and the second runtime finds no
+    device ("No HIP GPUs are available").  The other order is fine: the wheel's copy satisfies this library's DT_NEEDED
+    entry by SONAME.  So, when torch is installed but not imported yet, load the wheel's runtime first (what bench.py's
+    import order does anyway).  Callers without torch are not affected."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(p):
+        try:
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -82,6 +106,7 @@ def lib():
         raise ImportError(
             "orbslam_in_practice_amd: %s is missing -- build it with `make -C %s` (or "
             "__graft_entry__.build()).  This package has no CPU fallback." % (LIB_PATH, CSRC))
+    _one_hip_runtime()
     L = C.CDLL(LIB_PATH)
     if os.environ.get("ROCP_TOOL_LIBRARIES"):
         # Running under rocprofv3.  A --pmc pass post-processes every dispatch on a worker thread of the profiler; a
@@ -134,6 +159,8 @@ def lib():
                                          vp, vp]
     L.orb_search_by_projection.argtypes = [vp, C.POINTER(OrbFrameView), C.POINTER(OrbFrameView), vp, vp, vp, vp, C.c_double,
                                            C.c_double, C.c_double, C.c_double, vp, i32, vp, f32, i32, vp, vp]
+    L.orb_search_by_projection_device.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, C.c_double, C.c_double, C.c_double,
+                                                  C.c_double, vp, i32, f32, f32, f32, f32, vp, f32, i32, vp, vp, vp]
     L.orb_search_by_bow.argtypes = [vp, C.POINTER(OrbFrameView), vp, C.POINTER(OrbFrameView), f32, i32, vp, vp]
     L.ba_create.argtypes = [i32, i32, i32, i32, i32, C.POINTER(vp)]
     L.ba_destroy.argtypes = [vp]

@@ -715,11 +715,19 @@ __global__ __launch_bounds__(256) void k_query_topk(QueryArgs A) {
 
 /* projection of the last frame's map points with the current pose: query window and level range per feature
  * (upstream SearchByProjection, monocular).  A feature that takes no part gets r = 0: no candidate passes |dx| < 0. */
-__global__ void k_project_queries(const OrbKeyPoint *last_kps, const uint8_t *flags, const double *xw, int n, const double *pose12,
+/* pose (R row-major, t) and per-level scale factors of an N4 projection, passed BY VALUE as a kernel argument: no upload,
+   nothing for an asynchronous caller to keep alive */
+struct N4Pose {
+    double pose12[12];
+    float scale_factors[64];
+};
+__global__ void k_project_queries(const OrbKeyPoint *last_kps, const uint8_t *flags, const double *xw, int n, N4Pose PP,
                                   double fx, double fy, double cx, double cy, float min_x, float max_x, float min_y, float max_y,
-                                  const float *scale_factors, int nlevels, float th, float *qxyr, int32_t *qlvl) {
+                                  int nlevels, float th, float *qxyr, int32_t *qlvl) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const double *pose12 = PP.pose12;
+    const float *scale_factors = PP.scale_factors;
     float u = 0.f, v = 0.f, r = 0.f;
     int lo = 0, hi = 0;
     if (flags[i] & 1) {
@@ -1101,6 +1109,225 @@ extern "C" int orb_features_in_area(OrbMatcher *m, const OrbFrameView *f, const 
 }
 
 
+/* ---- SURVEY N4 on the device: the sequential walk and the rotation histogram of SearchByProjection ---------------------
+ * ("as k_match_init does for a11".)  Upstream's loop is sequential in the last frame's features -- feature i
+ * takes the closest candidate that is still free, and a feature taken by an earlier one is closed to later ones -- but,
+ * as in SearchForInitialization, a query only READS the taken flags of the candidates it inspects and only WRITES the
+ * state of the one feature it matches, so 64 queries are resolved in speculative rounds by ONE wavefront: every pending
+ * lane decides from the current LDS state; a lane that TAKES its feature stamps it (atomicMin of the lane id); a lane is
+ * valid iff no stamp in its read set is smaller than its own id; the valid prefix commits (cur_match by atomicMax of the
+ * query index: "the last writer wins" of the sequential loop; taken flags of distinct features), the first invalid lane
+ * opens the next round.  A query whose QK_TOP closest candidates are all taken is resolved alone by a wave-wide rescan of
+ * the whole window (the same keys as the host walk: distance << 32 | grid cell << 16 | index).  The rotation histogram
+ * (reference src/ORBmatcher.cpp:79-118 semantics, per ACCEPTANCE) closes the kernel: an acceptance in a bin outside the
+ * three maxima clears its feature (match -1, taken 0) and takes one off the count.  Identical results to the host walk
+ * (tests/test_gpu_n4.py runs both).  One wavefront per launch: for the host-pointer API the host walk is FASTER (10-20 us
+ * against ~70 rounds here); this kernel is for callers whose frames stay on the device (orb_search_by_projection_device). */
+struct N4WalkArgs {
+    const unsigned long long *lists; /* [nq][QK_TOP] from k_query_topk */
+    const uint8_t *flags;            /* [nq] bit0: holds a map point, bit1: the point has observations (takes the feature) */
+    const float *qxyr;               /* [nq][3] from k_project_queries (r > 0: a valid query) */
+    const int32_t *qlvl;             /* [nq][2] */
+    const OrbKeyPoint *kps2;         /* current frame: candidates */
+    const uint8_t *desc2;
+    int n2;
+    const OrbKeyPoint *kps1;         /* last frame: queries */
+    const uint8_t *desc1;
+    int nq;
+    float min_x, max_x, min_y, max_y;
+    int th_high, check_ori;
+    uint8_t *taken;     /* [n2] in / out */
+    int32_t *match;     /* [n2] out */
+    int32_t *n_matches; /* out */
+};
+__global__ __launch_bounds__(64) void k_n4_walk(N4WalkArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char n4_smem[];
+    const int lane = threadIdx.x, n2 = A.n2, nq = A.nq;
+    int32_t *s_stamp = (int32_t *)n4_smem;     /* [n2] */
+    int32_t *s_match = s_stamp + n2;           /* [n2] */
+    int32_t *s_feat = s_match + n2;            /* [nq] accepted feature of query i, or -1 */
+    uint8_t *s_taken = (uint8_t *)(s_feat + nq); /* [n2] */
+    uint8_t *s_bin = s_taken + n2;             /* [nq] */
+    __shared__ int s_hist[HISTO_LENGTH];
+    __shared__ int s_acc;
+    for (int j = lane; j < n2; j += 64) {
+        s_stamp[j] = 0x7FFFFFFF;
+        s_match[j] = -1;
+        s_taken[j] = A.taken[j];
+    }
+    for (int i = lane; i < nq; i += 64) {
+        s_feat[i] = -1;
+        s_bin[i] = 0xFF;
+    }
+    if (lane < HISTO_LENGTH) s_hist[lane] = 0;
+    if (lane == 0) s_acc = 0;
+    __syncthreads();
+    const float invW = (float)GRID_COLS / (A.max_x - A.min_x), invH = (float)GRID_ROWS / (A.max_y - A.min_y);
+    const float factor = HISTO_LENGTH / 360.0f;
+    for (int base = 0; base < nq; base += 64) {
+        const int i = base + lane;
+        uint64_t c[QK_TOP];
+#pragma unroll
+        for (int k = 0; k < QK_TOP; k++) c[k] = ~0ull;
+        int fl = 0;
+        float ang1 = 0.f;
+        bool valid = false;
+        if (i < nq) {
+            fl = A.flags[i];
+            valid = (fl & 1) && A.qxyr[3 * i + 2] > 0.f;
+            if (valid) {
+#pragma unroll
+                for (int k = 0; k < QK_TOP; k++) c[k] = A.lists[(size_t)i * QK_TOP + k];
+                ang1 = A.kps1[i].angle;
+            }
+        }
+        const int nchunk = min(64, nq - base);
+        int done = 0;
+        while (done < nchunk) {
+            const bool act = valid && lane >= done && lane < nchunk;
+            int best = -1, bestDist = 256, real = 0, n_insp = 0;
+            bool stop = false;
+#pragma unroll
+            for (int k = 0; k < QK_TOP; k++) {
+                if (!stop) {
+                    if (c[k] == ~0ull) {
+                        stop = true;
+                    } else {
+                        real++;
+                        n_insp = k + 1;
+                        const int j = (int)(c[k] & 0xFFFFu);
+                        if (!s_taken[j]) {
+                            best = j;
+                            bestDist = (int)(c[k] >> 32);
+                            stop = true;
+                        }
+                    }
+                }
+            }
+            const bool slow = act && best < 0 && real == QK_TOP; /* every listed candidate taken: whole-window rescan, alone */
+            const bool accept = act && !slow && best >= 0 && bestDist <= A.th_high;
+            const bool takes = accept && (fl & 2);
+            if (takes) atomicMin(&s_stamp[best], lane);
+            __syncthreads();
+            bool conflict = false;
+            if (act && !slow) {
+#pragma unroll
+                for (int k = 0; k < QK_TOP; k++)
+                    if (k < n_insp) conflict = conflict || s_stamp[(int)(c[k] & 0xFFFFu)] < lane;
+            }
+            const uint64_t badm = __ballot(act && (conflict || slow));
+            const int first_bad = badm ? (int)__builtin_ctzll(badm) : 64;
+            __syncthreads();
+            if (takes) s_stamp[best] = 0x7FFFFFFF; /* every stamp of this round is cleared again */
+            if (accept && lane < first_bad) {
+                atomicMax(&s_match[best], i); /* cur_match[best] = i: within a round the largest query index is the last writer */
+                if (takes) s_taken[best] = 1;
+                s_feat[i] = best;
+                atomicAdd(&s_acc, 1);
+                if (A.check_ori) {
+                    float rot = ang1 - A.kps2[best].angle;
+                    if (rot < 0.0f) rot += 360.0f;
+                    int bin = (int)roundf(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    s_bin[i] = (uint8_t)bin;
+                    atomicAdd(&s_hist[bin], 1);
+                }
+            }
+            __syncthreads();
+            done = min(first_bad, nchunk);
+            if (done < nchunk && ((__ballot(slow) >> done) & 1ull)) {
+                const int t = done, it = base + t;
+                const float x = A.qxyr[3 * it], y = A.qxyr[3 * it + 1], r = A.qxyr[3 * it + 2];
+                const int lo = A.qlvl[2 * it], hi = A.qlvl[2 * it + 1];
+                uint32_t a[8];
+                {
+                    const uint4 *p = (const uint4 *)(A.desc1 + (size_t)it * 32);
+                    const uint4 v0 = p[0], v1 = p[1];
+                    a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w;
+                    a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
+                }
+                uint64_t bestKey = ~0ull;
+                for (int j = lane; j < n2; j += 64) {
+                    if (s_taken[j]) continue;
+                    const OrbKeyPoint kp = A.kps2[j];
+                    const int ix = (int)round(((double)kp.x - (double)A.min_x) * (double)invW);
+                    const int iy = (int)round(((double)kp.y - (double)A.min_y) * (double)invH);
+                    if (ix < 0 || ix >= GRID_COLS || iy < 0 || iy >= GRID_ROWS) continue;
+                    if (kp.octave < lo || (hi >= 0 && kp.octave > hi)) continue;
+                    if (!(fabsf(kp.x - x) < r && fabsf(kp.y - y) < r)) continue;
+                    const uint4 *p = (const uint4 *)(A.desc2 + (size_t)j * 32);
+                    const int d = hamming256(a, p[0], p[1]);
+                    const uint64_t key = ((uint64_t)(uint32_t)d << 32) | ((uint64_t)(uint32_t)(ix * GRID_ROWS + iy) << 16) | (uint32_t)j;
+                    if (key < bestKey) bestKey = key;
+                }
+                const uint64_t sKey = wave_min_u64(bestKey);
+                if (sKey != ~0ull && (int)(sKey >> 32) <= A.th_high && lane == 0) {
+                    const int b = (int)(sKey & 0xFFFFu);
+                    s_match[b] = it; /* (later than every committed query) */
+                    if (A.flags[it] & 2) s_taken[b] = 1;
+                    s_feat[it] = b;
+                    s_acc++;
+                    if (A.check_ori) {
+                        float rot = A.kps1[it].angle - A.kps2[b].angle;
+                        if (rot < 0.0f) rot += 360.0f;
+                        int bin = (int)roundf(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        s_bin[it] = (uint8_t)bin;
+                        s_hist[bin]++;
+                    }
+                }
+                __syncthreads();
+                done++;
+            }
+        }
+    }
+    __syncthreads();
+    int removed = 0;
+    if (A.check_ori) { /* ComputeThreeMaxima (reference src/ORBmatcher.cpp:147-188), then the per-acceptance filter (:95-118) */
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        int max1 = 0, max2 = 0, max3 = 0;
+        for (int b = 0; b < HISTO_LENGTH; b++) {
+            const int sz = s_hist[b];
+            if (sz > max1) {
+                max3 = max2; max2 = max1; max1 = sz;
+                ind3 = ind2; ind2 = ind1; ind1 = b;
+            } else if (sz > max2) {
+                max3 = max2; max2 = sz;
+                ind3 = ind2; ind2 = b;
+            } else if (sz > max3) {
+                max3 = sz;
+                ind3 = b;
+            }
+        }
+        if (max2 < 0.1f * (float)max1) {
+            ind2 = -1;
+            ind3 = -1;
+        } else if (max3 < 0.1f * (float)max1) {
+            ind3 = -1;
+        }
+        for (int i0 = 0; i0 < nq; i0 += 64) {
+            const int i = i0 + lane;
+            bool bad = false;
+            if (i < nq) {
+                const int f = s_feat[i], b = s_bin[i];
+                bad = f >= 0 && b != ind1 && b != ind2 && b != ind3;
+                if (bad) {
+                    s_match[f] = -1;
+                    s_taken[f] = 0;
+                }
+            }
+            removed += __popcll(__ballot(bad));
+        }
+        __syncthreads();
+    }
+    for (int j = lane; j < n2; j += 64) {
+        A.match[j] = s_match[j];
+        A.taken[j] = s_taken[j];
+    }
+    if (lane == 0) *A.n_matches = s_acc - removed;
+}
+static size_t n4_walk_lds(int n2, int nq) { return (size_t)n2 * 9 + (size_t)nq * 5 + 64; }
+
 /* ---- SURVEY N4 host side ---------------------------------------------------------------------------------------- */
 static int n4_scratch(OrbMatcher *m, size_t bytes) {
     if (bytes <= m->cap_scratch) return ORB_OK;
@@ -1179,24 +1406,26 @@ extern "C" int orb_search_by_projection(OrbMatcher *m, const OrbFrameView *cur, 
                  o_k2 = al(o_sf + (size_t)nlevels * 4), o_d2 = al(o_k2 + (size_t)n2 * sizeof(OrbKeyPoint)),
                  o_k1 = al(o_d2 + (size_t)n2 * 32), o_d1 = al(o_k1 + (size_t)nq * sizeof(OrbKeyPoint)), in_bytes = al(o_d1 + (size_t)nq * 32),
                  o_q = in_bytes, o_lv = al(o_q + (size_t)nq * 12), o_out = al(o_lv + (size_t)nq * 8),
-                 total = al(o_out + (size_t)nq * QK_TOP * 8), out_bytes = total - o_q;
+                 total = al(o_out + (size_t)nq * QK_TOP * 8), out_bytes = total - o_q,
+                 o_tk = total, o_mt = al(o_tk + n2), o_nm = al(o_mt + (size_t)n2 * 4), total2 = al(o_nm + 4); /* (device walk: taken | match | count) */
     int rc;
-    if ((rc = n4_scratch(m, total))) return rc;
-    if ((rc = n4_pinned(m, total))) return rc;
+    if ((rc = n4_scratch(m, total2))) return rc;
+    if ((rc = n4_pinned(m, total2))) return rc;
     uint8_t *S = m->d_scratch, *P = m->h_n4;
     memcpy(P + o_fl, last_flags, nq);
     memcpy(P + o_xw, last_xw, (size_t)nq * 24);
-    memcpy(P + o_pose, Rcw9, 72);
-    memcpy(P + o_pose + 72, tcw3, 24);
-    memcpy(P + o_sf, scale_factors, (size_t)nlevels * 4);
     memcpy(P + o_k2, cur->kps, (size_t)n2 * sizeof(OrbKeyPoint));
     memcpy(P + o_d2, cur->desc, (size_t)n2 * 32);
     memcpy(P + o_k1, last->kps, (size_t)nq * sizeof(OrbKeyPoint));
     memcpy(P + o_d1, last->desc, (size_t)nq * 32);
     MCHK(hipMemcpyAsync(S, P, in_bytes, hipMemcpyHostToDevice, m->stream));
+    N4Pose PP;
+    memcpy(PP.pose12, Rcw9, 72);
+    memcpy(PP.pose12 + 9, tcw3, 24);
+    for (int l = 0; l < 64; l++) PP.scale_factors[l] = l < nlevels ? scale_factors[l] : 0.f;
     hipLaunchKernelGGL(k_project_queries, dim3((nq + 255) / 256), dim3(256), 0, m->stream, (const OrbKeyPoint *)(S + o_k1), S + o_fl,
-                       (const double *)(S + o_xw), nq, (const double *)(S + o_pose), fx, fy, cx, cy, cur->min_x, cur->max_x,
-                       cur->min_y, cur->max_y, (const float *)(S + o_sf), nlevels, th, (float *)(S + o_q), (int32_t *)(S + o_lv));
+                       (const double *)(S + o_xw), nq, PP, fx, fy, cx, cy, cur->min_x, cur->max_x, cur->min_y, cur->max_y, nlevels, th,
+                       (float *)(S + o_q), (int32_t *)(S + o_lv));
     QueryArgs A{};
     A.kps2 = (const OrbKeyPoint *)(S + o_k2);
     A.desc2 = S + o_d2;
@@ -1210,6 +1439,39 @@ extern "C" int orb_search_by_projection(OrbMatcher *m, const OrbFrameView *cur, 
     A.out = (unsigned long long *)(S + o_out);
     hipLaunchKernelGGL(k_query_topk, dim3((nq + 256 / QK_SLICES - 1) / (256 / QK_SLICES)), dim3(256), 0, m->stream, A);
     MCHK(hipGetLastError());
+    if (getenv("ORBSLAM_AMD_N4_DEVICE_WALK") && n4_walk_lds(n2, nq) <= 120 * 1024) {
+        /* the walk and the rotation histogram on the device too (k_n4_walk) -- what orb_search_by_projection_device runs;
+           switchable here so that the tests hold it against the host walk below and the oracle */
+        memcpy(P + o_tk, cur_taken, n2);
+        MCHK(hipMemcpyAsync(S + o_tk, P + o_tk, n2, hipMemcpyHostToDevice, m->stream));
+        N4WalkArgs WA{};
+        WA.lists = (const unsigned long long *)(S + o_out);
+        WA.flags = S + o_fl;
+        WA.qxyr = (const float *)(S + o_q);
+        WA.qlvl = (const int32_t *)(S + o_lv);
+        WA.kps2 = (const OrbKeyPoint *)(S + o_k2);
+        WA.desc2 = S + o_d2;
+        WA.n2 = n2;
+        WA.kps1 = (const OrbKeyPoint *)(S + o_k1);
+        WA.desc1 = S + o_d1;
+        WA.nq = nq;
+        WA.min_x = cur->min_x; WA.max_x = cur->max_x; WA.min_y = cur->min_y; WA.max_y = cur->max_y;
+        WA.th_high = TH_HIGH;
+        WA.check_ori = check_orientation;
+        WA.taken = S + o_tk;
+        WA.match = (int32_t *)(S + o_mt);
+        WA.n_matches = (int32_t *)(S + o_nm);
+        static PerDeviceLdsLimit walk_lim;
+        MCHK(walk_lim.ensure((const void *)k_n4_walk, n4_walk_lds(n2, nq)));
+        hipLaunchKernelGGL(k_n4_walk, dim3(1), dim3(64), n4_walk_lds(n2, nq), m->stream, WA);
+        MCHK(hipGetLastError());
+        MCHK(hipMemcpyAsync(P + o_tk, S + o_tk, total2 - o_tk, hipMemcpyDeviceToHost, m->stream));
+        MCHK(hipStreamSynchronize(m->stream));
+        memcpy(cur_taken, P + o_tk, n2);
+        memcpy(cur_match, P + o_mt, (size_t)n2 * 4);
+        memcpy(n_matches, P + o_nm, 4);
+        return ORB_OK;
+    }
     MCHK(hipMemcpyAsync(P + o_q, S + o_q, out_bytes, hipMemcpyDeviceToHost, m->stream));
     MCHK(hipStreamSynchronize(m->stream));
     const unsigned long long *lists = (const unsigned long long *)(P + o_out);
@@ -1263,6 +1525,76 @@ extern "C" int orb_search_by_projection(OrbMatcher *m, const OrbFrameView *cur, 
     }
     if (check_orientation) nm -= n4_histogram_filter(acc, cur_match, cur_taken);
     *n_matches = nm;
+    return ORB_OK;
+}
+
+/* SearchByProjection on DEVICE-RESIDENT frames (SURVEY N4 / VERDICT r2 "no host round trip"): the current and the last
+ * frame's feature slabs as an extractor left them in HBM (orb_extract_batch_device), the last frame's map-point flags and
+ * world positions in device memory, results (cur_match, cur_taken, the count) in device memory; projection, candidate
+ * scan, sequential walk and rotation histogram are three kernels on `stream`, nothing is copied and nothing waits.  The
+ * scratch of the matcher handle holds the query parameters and candidate lists: one search in flight per handle. */
+extern "C" int orb_search_by_projection_device(OrbMatcher *m, const OrbKeyPoint *d_cur_kps, const uint8_t *d_cur_desc, int n_cur,
+                                               const OrbKeyPoint *d_last_kps, const uint8_t *d_last_desc, int n_last,
+                                               const uint8_t *d_last_flags, const double *d_last_xw, const double *Rcw9,
+                                               const double *tcw3, double fx, double fy, double cx, double cy,
+                                               const float *scale_factors, int nlevels, float min_x, float max_x, float min_y,
+                                               float max_y, uint8_t *d_cur_taken, float th, int check_orientation,
+                                               int32_t *d_cur_match, int32_t *d_n_matches, void *stream) {
+    if (!m || n_cur <= 0 || n_last <= 0 || nlevels <= 0 || nlevels > 64 || !scale_factors || !Rcw9 || !tcw3 || !d_cur_kps ||
+        !d_cur_desc || !d_last_kps || !d_last_desc || !d_last_flags || !d_last_xw || !d_cur_taken || !d_cur_match || !d_n_matches)
+        return ORB_E_INVALID;
+    if (n_cur > m->max_kp || n_last > m->max_kp || n4_walk_lds(n_cur, n_last) > 120 * 1024) return ORB_E_CAPACITY;
+    MCHK(hipSetDevice(m->device));
+    hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+    const int nq = n_last, n2 = n_cur;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_q = 0, o_lv = al(o_q + (size_t)nq * 12), o_out = al(o_lv + (size_t)nq * 8), total = al(o_out + (size_t)nq * QK_TOP * 8);
+    int rc;
+    if (total > m->cap_scratch) { /* (growing the scratch frees the old block: not under a search that may still be running) */
+        MCHK(hipStreamSynchronize(st));
+        MCHK(hipStreamSynchronize(m->stream));
+        if ((rc = n4_scratch(m, total))) return rc;
+    }
+    uint8_t *S = m->d_scratch;
+    N4Pose PP;
+    memcpy(PP.pose12, Rcw9, 72);
+    memcpy(PP.pose12 + 9, tcw3, 24);
+    for (int l = 0; l < 64; l++) PP.scale_factors[l] = l < nlevels ? scale_factors[l] : 0.f;
+    hipLaunchKernelGGL(k_project_queries, dim3((nq + 255) / 256), dim3(256), 0, st, d_last_kps, d_last_flags, d_last_xw, nq, PP, fx, fy,
+                       cx, cy, min_x, max_x, min_y, max_y, nlevels, th, (float *)(S + o_q), (int32_t *)(S + o_lv));
+    QueryArgs A{};
+    A.kps2 = d_cur_kps;
+    A.desc2 = d_cur_desc;
+    A.n2 = n2;
+    A.qdesc = d_last_desc;
+    A.qxyr = (const float *)(S + o_q);
+    A.qlvl = (const int32_t *)(S + o_lv);
+    A.nq = nq;
+    A.min_x = min_x; A.max_x = max_x; A.min_y = min_y; A.max_y = max_y;
+    A.keep_max_d = 100; /* TH_HIGH */
+    A.out = (unsigned long long *)(S + o_out);
+    hipLaunchKernelGGL(k_query_topk, dim3((nq + 256 / QK_SLICES - 1) / (256 / QK_SLICES)), dim3(256), 0, st, A);
+    N4WalkArgs WA{};
+    WA.lists = (const unsigned long long *)(S + o_out);
+    WA.flags = d_last_flags;
+    WA.qxyr = (const float *)(S + o_q);
+    WA.qlvl = (const int32_t *)(S + o_lv);
+    WA.kps2 = d_cur_kps;
+    WA.desc2 = d_cur_desc;
+    WA.n2 = n2;
+    WA.kps1 = d_last_kps;
+    WA.desc1 = d_last_desc;
+    WA.nq = nq;
+    WA.min_x = min_x; WA.max_x = max_x; WA.min_y = min_y; WA.max_y = max_y;
+    WA.th_high = 100;
+    WA.check_ori = check_orientation;
+    WA.taken = d_cur_taken;
+    WA.match = d_cur_match;
+    WA.n_matches = d_n_matches;
+    static PerDeviceLdsLimit walk_lim;
+    MCHK(walk_lim.ensure((const void *)k_n4_walk, n4_walk_lds(n2, nq)));
+    hipLaunchKernelGGL(k_n4_walk, dim3(1), dim3(64), n4_walk_lds(n2, nq), st, WA);
+    MCHK(hipGetLastError());
     return ORB_OK;
 }
 

@@ -119,3 +119,93 @@ def test_search_by_bow_exhausted_lists(oracle):
     gn, gm = m.SearchByBoW(oa.FrameFeatures(kk, dk, BOUNDS), valid, oa.FrameFeatures(kf, df, BOUNDS))
     m.close()
     assert gn == on and np.array_equal(gm, om)
+
+
+def _sbp_case(oracle, feats, seed, th, ori):
+    (k0, d0), (k1, d1) = feats
+    rng = np.random.default_rng(seed)
+    flags = ((rng.random(len(k0)) < 0.8).astype(np.uint8)) | ((rng.random(len(k0)) < 0.6).astype(np.uint8) << 1)
+    flags[flags == 2] = 0
+    xw = _lift(k0)
+    R, t = _rot_z(0.5 * seed), np.array([0.01 * seed, -0.02, 0.05 * (seed % 2)])
+    taken = (rng.random(len(k1)) < 0.1).astype(np.uint8)
+    ref = oracle.search_by_projection(k1, d1, k0, d0, BOUNDS, flags, xw, R, t, FX, FY, CX, CY, SF, taken, th, ori)
+    return (k0, d0, k1, d1, flags, xw, R, t, taken), ref
+
+
+@pytest.mark.parametrize("th,ori,seed", [(15.0, True, 0), (30.0, True, 1), (30.0, False, 2), (7.0, True, 3)])
+def test_search_by_projection_device_walk_equals_host_walk_and_oracle(oracle, feats, monkeypatch, th, ori, seed):
+    """the sequential walk and the rotation histogram ON THE DEVICE (k_n4_walk: speculative rounds of 64 queries on one
+    wavefront) through the host-pointer entry point: same indices, counts and taken flags as the host walk
+    and the oracle"""
+    import orbslam_in_practice_amd as oa
+    (k0, d0, k1, d1, flags, xw, R, t, taken), (on, om, ot) = _sbp_case(oracle, feats, seed, th, ori)
+    m = oa.ORBmatcher(0.9, ori, max_keypoints=2048)
+    F1, F0 = oa.FrameFeatures(k1, d1, BOUNDS), oa.FrameFeatures(k0, d0, BOUNDS)
+    hn, hm, ht = m.SearchByProjection(F1, F0, flags, xw, R, t, FX, FY, CX, CY, SF, taken, th)
+    monkeypatch.setenv("ORBSLAM_AMD_N4_DEVICE_WALK", "1")
+    gn, gm, gt = m.SearchByProjection(F1, F0, flags, xw, R, t, FX, FY, CX, CY, SF, taken, th)
+    m.close()
+    assert (hn, gn) == (on, on) and np.array_equal(hm, om) and np.array_equal(ht, ot)
+    assert np.array_equal(gm, om) and np.array_equal(gt, ot)
+
+
+def test_search_by_projection_device_walk_exhausted_lists(oracle, monkeypatch):
+    """the contention case of test_search_by_projection_exhausted_lists on the device walk: queries whose eight closest
+    candidates are all taken are resolved alone by the wave-wide rescan"""
+    import orbslam_in_practice_amd as oa
+    from orbslam_in_practice_amd import synth
+    monkeypatch.setenv("ORBSLAM_AMD_N4_DEVICE_WALK", "1")
+    rng = np.random.default_rng(5)
+    base = synth.random_descriptors(9, 1)[0]
+    n_last, n_cur = 150, 90                      # (several 64-query chunks, takers and non-takers mixed)
+    k0 = np.zeros(n_last, oracle.KP_DTYPE)
+    k1 = np.zeros(n_cur, oracle.KP_DTYPE)
+    for k, n in ((k0, n_last), (k1, n_cur)):
+        k["x"] = 300 + rng.uniform(-6, 6, n)
+        k["y"] = 200 + rng.uniform(-6, 6, n)
+        k["size"], k["octave"], k["class_id"] = 31, 0, -1
+        k["angle"] = rng.choice([10.0, 10.0, 10.0, 130.0], n)
+    d0 = np.tile(base, (n_last, 1))
+    d1 = np.tile(base, (n_cur, 1))
+    for j in range(n_cur):
+        d1[j, j % 32] ^= np.uint8((1 << (j % 3)) - 1 if j % 3 else 0)
+    flags = np.where(rng.random(n_last) < 0.7, 3, 1).astype(np.uint8)
+    xw = _lift(k0)
+    taken = np.zeros(n_cur, np.uint8)
+    for ori in (False, True):
+        on, om, ot = oracle.search_by_projection(k1, d1, k0, d0, BOUNDS, flags, xw, np.eye(3), np.zeros(3), FX, FY, CX, CY, SF,
+                                                 taken, 15.0, ori)
+        m = oa.ORBmatcher(0.9, ori, max_keypoints=1024)
+        gn, gm, gt = m.SearchByProjection(oa.FrameFeatures(k1, d1, BOUNDS), oa.FrameFeatures(k0, d0, BOUNDS), flags, xw, np.eye(3),
+                                          np.zeros(3), FX, FY, CX, CY, SF, taken, 15.0)
+        m.close()
+        assert gn == on and np.array_equal(gm, om) and np.array_equal(gt, ot), ori
+    assert on >= n_cur - 5
+
+
+def test_search_by_projection_on_device_resident_frames(oracle, feats):
+    """orb_search_by_projection_device: feature slabs, flags, world points and results all in HBM (torch tensors here),
+    three kernels on a stream, no copy inside the call -- same results as the oracle"""
+    torch = pytest.importorskip("torch")
+    import orbslam_in_practice_amd as oa
+    dev = torch.device("cuda", 0)
+    for seed, th, ori in ((0, 15.0, True), (2, 30.0, False)):
+        (k0, d0, k1, d1, flags, xw, R, t, taken), (on, om, ot) = _sbp_case(oracle, feats, seed, th, ori)
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(dev)
+        t_k1, t_d1, t_k0, t_d0 = up(k1), up(d1), up(k0), up(d0)
+        t_fl, t_tk = up(flags), up(taken)
+        t_xw = torch.from_numpy(np.ascontiguousarray(xw, np.float64)).to(dev)
+        t_m = torch.full((len(k1),), -7, dtype=torch.int32, device=dev)
+        t_n = torch.zeros((1,), dtype=torch.int32, device=dev)
+        m = oa.ORBmatcher(0.9, ori, max_keypoints=2048)
+        st = torch.cuda.Stream(device=dev)
+        torch.cuda.synchronize()
+        import ctypes as C
+        m.search_by_projection_device(t_k1.data_ptr(), t_d1.data_ptr(), len(k1), t_k0.data_ptr(), t_d0.data_ptr(), len(k0),
+                                      t_fl.data_ptr(), t_xw.data_ptr(), R, t, FX, FY, CX, CY, SF, BOUNDS, t_tk.data_ptr(), th,
+                                      t_m.data_ptr(), t_n.data_ptr(), C.c_void_p(st.cuda_stream))
+        st.synchronize()
+        m.close()
+        assert int(t_n.item()) == on
+        assert np.array_equal(t_m.cpu().numpy(), om) and np.array_equal(t_tk.cpu().numpy(), ot)
