@@ -19,7 +19,11 @@ reported under `local_ba` with its own roofline, CPU baseline and the one-window
 
 Rank 0 prints ONE JSON line (driver contract) with `roofline` (dominant kernel, HIP-event durations measured in a
 separate pass after the timed region) and, at N == 1, `cpu_baseline` (the CPU oracle -- a port of the reference path --
-timed on a bounded sample on this box's host cores).
+timed on a bounded sample on this box's host cores).  The oracle is also the CHECKER of the timed regions' own outputs:
+`parity` (slab rows and match rows of the last timed batch, bit-exact) and `local_ba.parity` (windows of the last
+streamed batch within 1e-5); a mismatch makes the exit code 3.  `single_stream` is the reference's real call pattern
+(one frame at a time through the drop-in C++ classes, tests/cpp/tracking_main.cpp) run as a child process before this
+one creates its HIP queues; `tracking_loop` the same chain with Python in the loop, one stream per rank.
 """
 import argparse
 import ctypes as C

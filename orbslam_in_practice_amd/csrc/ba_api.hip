@@ -213,6 +213,64 @@ __device__ __forceinline__ void se3_exp_mul(const double u[6], const double *pin
 #pragma unroll
     for (int i = 0; i < 3; i++) pout[4 + i] = te[i] + RE[i * 3] * ti[0] + RE[i * 3 + 1] * ti[1] + RE[i * 3 + 2] * ti[2];
 }
+/* The same update for the pose-only optimisation, whose 40 LM iterations each wait for it (k_pose_opt: solve + exp map were
+ * half of an iteration).  Same mathematics, shorter dependent chain: no f64 square root or division (v_rsq_f64 / v_rcp-free
+ * reciprocals by one cubically convergent step), ONE sincos -- of the half angle -- from which the quaternion of exp(omega)
+ * follows directly (cos(t/2), sin(t/2) omega / t) instead of through a rotation matrix, Eigen's matrix-to-quaternion branch,
+ * a normalisation and back to a matrix; sin t = 2 s c and 1 - cos t = 2 s^2 feed R and V.  Differs from se3_exp_mul (which
+ * follows g2o's operation sequence, and stays in the BA kernels) by rounding only. */
+__device__ __forceinline__ double po_rsqrt(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    const double e = __builtin_fma(-(x * r), r, 1.0);
+    return __builtin_fma(r, __builtin_fma(0.375, e, 0.5) * e, r);
+}
+__device__ __forceinline__ void se3_exp_mul_fast(const double u[6], const double *pin, double *pout) {
+    const double wx = u[0], wy = u[1], wz = u[2];
+    const double theta2 = wx * wx + wy * wy + wz * wz;
+    if (theta2 < 1e-10) { /* the small-angle branch of SE3Quat::exp (theta < 1e-5): rare, the general code */
+        se3_exp_mul(u, pin, pout);
+        return;
+    }
+    const double it = po_rsqrt(theta2), theta = theta2 * it, it2 = it * it;
+    double sh, ch;
+    sincos(0.5 * theta, &sh, &ch);
+    const double st = 2.0 * sh * ch, omc = 2.0 * sh * sh; /* sin t, 1 - cos t */
+    const double a = st * it, b = omc * it2, c = (theta - st) * it2 * it;
+    const double O[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+    double O2[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) O2[i * 3 + j] = O[i * 3] * O[j] + O[i * 3 + 1] * O[3 + j] + O[i * 3 + 2] * O[6 + j];
+    double RE[9], V[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        RE[i] = (i % 4 == 0 ? 1.0 : 0.0) + a * O[i] + b * O2[i];
+        V[i] = (i % 4 == 0 ? 1.0 : 0.0) + b * O[i] + c * O2[i];
+    }
+    const double k = sh * it; /* sin(t/2) / t; cos(t/2) > 0 for every step an LM iteration takes (t < pi) */
+    double qe[4] = {ch, k * wx, k * wy, k * wz};
+    if (qe[0] < 0) {
+        qe[0] = -qe[0]; qe[1] = -qe[1]; qe[2] = -qe[2]; qe[3] = -qe[3];
+    }
+    double te[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) te[i] = V[i * 3] * u[3] + V[i * 3 + 1] * u[4] + V[i * 3 + 2] * u[5];
+    const double *qi = pin, *ti = pin + 4;
+    double qo[4];
+    qo[0] = qe[0] * qi[0] - qe[1] * qi[1] - qe[2] * qi[2] - qe[3] * qi[3];
+    qo[1] = qe[0] * qi[1] + qe[1] * qi[0] + qe[2] * qi[3] - qe[3] * qi[2];
+    qo[2] = qe[0] * qi[2] - qe[1] * qi[3] + qe[2] * qi[0] + qe[3] * qi[1];
+    qo[3] = qe[0] * qi[3] + qe[1] * qi[2] - qe[2] * qi[1] + qe[3] * qi[0];
+    if (qo[0] < 0) {
+        qo[0] = -qo[0]; qo[1] = -qo[1]; qo[2] = -qo[2]; qo[3] = -qo[3];
+    }
+    const double rn = po_rsqrt(qo[0] * qo[0] + qo[1] * qo[1] + qo[2] * qo[2] + qo[3] * qo[3]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) pout[i] = qo[i] * rn;
+#pragma unroll
+    for (int i = 0; i < 3; i++) pout[4 + i] = te[i] + RE[i * 3] * ti[0] + RE[i * 3 + 1] * ti[1] + RE[i * 3 + 2] * ti[2];
+}
 __device__ __forceinline__ void project_err(const double *pose, const double *X, const double *ob, double fx, double fy,
                                             double cx, double cy, double e[2], double pc[3]) {
     double R[9];
@@ -4309,7 +4367,7 @@ __device__ __forceinline__ bool po_chol6_solve(const double *H, double lambda, c
 __global__ __launch_bounds__(PO_T) void k_pose_opt(double *pose7_all, const double *xw_all, const double *obs_all,
                                                     const double *info_all, uint8_t *fl_all, uint8_t *outlier_all,
                                                     const int32_t *offs, double fx, double fy, double cx, double cy,
-                                                    int32_t *n_inliers_all, int lds_edges) {
+                                                    int32_t *n_inliers_all, int lds_edges, int timing) {
     /* one workgroup per pose problem: problem p owns edges [offs[p], offs[p+1]) */
     __shared__ POShared s;
     __shared__ double po_tr[28][PO_TR_LD];
@@ -4351,6 +4409,15 @@ __global__ __launch_bounds__(PO_T) void k_pose_opt(double *pose7_all, const doub
     }
     __syncthreads();
     quat_normalize(pose);
+    /* (timing != 0: thread 0 times the sections of an LM iteration -- s_memrealtime ticks of 10 ns -- and prints them) */
+    unsigned long long tJ = 0, tR = 0, tS = 0, tC = 0, tq0 = 0, tq1;
+    int nits = 0;
+#define PO_TM(acc)                                   \
+    if (timing) {                                    \
+        tq1 = __builtin_amdgcn_s_memrealtime();      \
+        acc += tq1 - tq0;                            \
+        tq0 = tq1;                                   \
+    }
     int nBads = 0;
     double lambda = 0, ni = 2;
     for (int it = 0; it < 4; it++) {
@@ -4365,6 +4432,8 @@ __global__ __launch_bounds__(PO_T) void k_pose_opt(double *pose7_all, const doub
             double acc[28];
 #pragma unroll
             for (int i = 0; i < 28; i++) acc[i] = 0;
+            if (timing) tq0 = __builtin_amdgcn_s_memrealtime();
+            nits++;
             for (int i = tid; i < n; i += PO_T) {
                 if (!(fl[i] & 1)) continue;
                 double e[2], pc[3], Ji[6], Jj[12];
@@ -4387,7 +4456,9 @@ __global__ __launch_bounds__(PO_T) void k_pose_opt(double *pose7_all, const doub
                 acc[27] += 1.0;
             }
             double tot[28];
+            PO_TM(tJ)
             po_reduce28(acc, po_tr, s, tot);
+            PO_TM(tR)
             if (tot[27] == 0.0) break;
             double H[36], b[6];
             {
@@ -4417,12 +4488,14 @@ __global__ __launch_bounds__(PO_T) void k_pose_opt(double *pose7_all, const doub
                 double x[6];
                 const bool ok2 = po_chol6_solve(H, lambda, b, x);
                 if (ok2) {
-                    se3_exp_mul(x, pose, trial);
+                    se3_exp_mul_fast(x, pose, trial);
                 } else {
 #pragma unroll
                     for (int i = 0; i < 7; i++) trial[i] = pose[i];
                 }
+                PO_TM(tS)
                 double tempChi = po_chi2(trial, xw, obs, info, fl, n, fx, fy, cx, cy, delta, s);
+                PO_TM(tC)
                 if (!ok2) tempChi = 1.7976931348623157e308;
                 double scale = 0;
                 if (ok2)
@@ -4476,6 +4549,9 @@ __global__ __launch_bounds__(PO_T) void k_pose_opt(double *pose7_all, const doub
         for (int i = 0; i < 7; i++) pose7[i] = pose[i];
     }
     if (tid == 0) *n_inliers = n - nBads;
+    if (timing && tid == 0 && blockIdx.x == 0)
+        printf("[pose opt] n %d, %d iterations, us per iteration: jacobians + H %.2f | reduce28 %.2f | solve + exp map %.2f | trial chi2 %.2f\n", n,
+               nits, tJ * 0.01 / nits, tR * 0.01 / nits, tS * 0.01 / nits, tC * 0.01 / nits);
 }
 
 /* n_problems independent pose problems; problem p owns edges [offsets[p], offsets[p+1]) of xw/obs/inv_sigma2/
@@ -4524,7 +4600,7 @@ extern "C" int ba_pose_optimization_batch(BASolver *s, double *poses, const doub
     }
     hipLaunchKernelGGL(k_pose_opt, dim3(n_problems), dim3(PO_T), lds_edges ? po_lds : 0, s->stream, d_pose, (const double *)d_xw,
                        (const double *)d_obs, (const double *)d_info, d_fl, d_out, (const int32_t *)d_offs, fx, fy, cx, cy,
-                       d_ninl, lds_edges);
+                       d_ninl, lds_edges, getenv("ORBSLAM_AMD_PO_TIMING") ? 1 : 0);
     BCHK(hipGetLastError());
     BCHK(hipMemcpyAsync(s->ppD, d_pose, (size_t)n_problems * 56, hipMemcpyDeviceToHost, s->stream));
     if (n > 0) BCHK(hipMemcpyAsync(s->ppB, d_out, (size_t)n, hipMemcpyDeviceToHost, s->stream));
