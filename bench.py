@@ -213,7 +213,7 @@ def single_stream(n_frames):
         # the child is not part of a profiling session of this process (rocprofv3 preloads its tool through the environment)
         env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF"))}
         best = None
-        for _ in range(2):   # the first run pages the binary and the library in
+        for _ in range(4):   # the first run pages the binary and the library in, and an idle GPU takes a few hundred ms to clock up
             p = subprocess.run([exe, str(frames.shape[2]), str(frames.shape[1]), str(n_frames), td + "/f.raw", td + "/gt.bin",
                                 *("%.17g" % v for v in K), td + "/out.bin"], capture_output=True, text=True, timeout=300, env=env)
             if p.returncode != 0:
