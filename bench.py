@@ -201,40 +201,52 @@ def single_stream(n_frames):
     import subprocess
     import tempfile
     from orbslam_in_practice_amd import sequence as sq
-    exe = os.path.join(ROOT, "tests", "cpp", "build", "tracking_main")
+    import __graft_entry__ as ge
     try:
-        if not os.path.exists(exe):
-            import __graft_entry__ as ge
-            ge.build_cpp_loop()
+        exe = ge.build_cpp_loop("tracking_main")
+        exe2 = ge.build_cpp_loop("tracker_main")
         td = tempfile.mkdtemp()
         frames, gt, K, _ = sq.make_plane_sequence(5, n_frames)
         frames.tofile(td + "/f.raw")
         gt.astype(np.float64).tofile(td + "/gt.bin")
         # the child is not part of a profiling session of this process (rocprofv3 preloads its tool through the environment)
         env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF"))}
-        best = None
-        for _ in range(4):   # the first run pages the binary and the library in, and an idle GPU takes a few hundred ms to clock up
-            p = subprocess.run([exe, str(frames.shape[2]), str(frames.shape[1]), str(n_frames), td + "/f.raw", td + "/gt.bin",
-                                *("%.17g" % v for v in K), td + "/out.bin"], capture_output=True, text=True, timeout=300, env=env)
-            if p.returncode != 0:
-                return {"error": "tracking_main exited with %d: %s" % (p.returncode, p.stderr[-200:])}
-            j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
-            if best is None or j["secs"] < best["secs"]:
-                best = j
-        raw = open(td + "/out.bin", "rb").read()
-        rec = np.frombuffer(raw, np.dtype([("pose", "<f8", 7), ("nm", "<i4"), ("inl", "<i4")]), n_frames, 4)
-        j = best
+        rec_dt = np.dtype([("pose", "<f8", 7), ("nm", "<i4"), ("inl", "<i4")])
+
+        def run(binary, out):
+            best = None
+            for _ in range(4):   # the first run pages the binary and the library in, and an idle GPU takes a few hundred ms to clock up
+                p = subprocess.run([binary, str(frames.shape[2]), str(frames.shape[1]), str(n_frames), td + "/f.raw", td + "/gt.bin",
+                                    *("%.17g" % v for v in K), out], capture_output=True, text=True, timeout=300, env=env)
+                if p.returncode != 0:
+                    raise RuntimeError("%s exited with %d: %s" % (os.path.basename(binary), p.returncode, p.stderr[-200:]))
+                j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+                if best is None or j["secs"] < best["secs"]:
+                    best = j
+            return best, np.frombuffer(open(out, "rb").read(), rec_dt, n_frames, 4)
+
+        j, rec = run(exe, td + "/out.bin")
         track_s = j["secs"] - j["t_first"] - j["t_ba"]
-        return {"value": round((n_frames - 1) / track_s, 1), "unit": "frames/s",
-                "what": "tracking alone: Frame(im,&extractor) -> SearchByProjection -> PoseOptimization per frame, C++ on the drop-in classes",
-                "with_local_ba_frames_per_s": round((n_frames - 1) / (j["secs"] - j["t_first"]), 1),
-                "per_call_ms": {"Frame(im,&extractor)": round(j["ms_extract"], 4), "SearchByProjection": round(j["ms_sbp"], 4),
-                                "PoseOptimization": round(j["ms_po"], 4),
-                                "LocalBundleAdjustment": round(j["t_ba"] / max(j["ba_runs"], 1) * 1e3, 3)},
-                "local_ba_runs": j["ba_runs"], "map_points": j["map_points"],
-                "ate_rmse_m": round(sq.ate_rmse(rec["pose"].copy(), gt), 5), "mean_matches": round(float(rec["nm"][1:].mean()), 1),
-                "workload": "%d synthetic frames %dx%d, %d features, keyframe every 4 frames, local BA over the covisibility window"
-                            % (n_frames, frames.shape[2], frames.shape[1], NFEATURES)}
+        res = {"value": round((n_frames - 1) / track_s, 1), "unit": "frames/s",
+               "what": "tracking alone: Frame(im,&extractor) -> SearchByProjection -> PoseOptimization per frame, C++ on the drop-in classes",
+               "with_local_ba_frames_per_s": round((n_frames - 1) / (j["secs"] - j["t_first"]), 1),
+               "per_call_ms": {"Frame(im,&extractor)": round(j["ms_extract"], 4), "SearchByProjection": round(j["ms_sbp"], 4),
+                               "PoseOptimization": round(j["ms_po"], 4),
+                               "LocalBundleAdjustment": round(j["t_ba"] / max(j["ba_runs"], 1) * 1e3, 3)},
+               "local_ba_runs": j["ba_runs"], "map_points": j["map_points"],
+               "ate_rmse_m": round(sq.ate_rmse(rec["pose"].copy(), gt), 5), "mean_matches": round(float(rec["nm"][1:].mean()), 1),
+               "workload": "%d synthetic frames %dx%d, %d features, keyframe every 4 frames, local BA over the covisibility window"
+                           % (n_frames, frames.shape[2], frames.shape[1], NFEATURES)}
+        # the same three steps per frame as ONE device chain (orb_tracker_track: one round trip instead of three; no local BA)
+        j2, rec2 = run(exe2, td + "/out2.bin")
+        res["device_chain"] = {"value": round((n_frames - 1) / j2["track_secs"], 1), "unit": "frames/s",
+                               "ms_per_frame": round(j2["track_secs"] / (n_frames - 1) * 1e3, 4),
+                               "what": "orb_tracker_track per frame (tests/cpp/tracker_main.cpp): extraction, SearchByProjection with the walk "
+                                       "on the device and PoseOptimization of the matches chained on one stream, one synchronisation",
+                               "ate_rmse_m": round(sq.ate_rmse(rec2["pose"].copy(), gt), 5),
+                               "mean_matches": round(float(rec2["nm"][1:].mean()), 1),
+                               "mean_inliers": round(float(rec2["inl"][1:].mean()), 1)}
+        return res
     except Exception as e:   # a missing host compiler must not cost the driver its line
         return {"error": "%s: %s" % (type(e).__name__, e)}
 

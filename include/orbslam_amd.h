@@ -184,9 +184,12 @@ int orb_search_by_projection(OrbMatcher *m, const OrbFrameView *cur, const OrbFr
  * Projection, candidate scan, the sequential walk (speculative rounds on one wavefront, k_n4_walk) and the rotation
  * histogram run as three kernels on `stream` (NULL = the matcher's): no copy, no synchronisation.  Identical results to
  * orb_search_by_projection.  ORB_E_CAPACITY beyond ~8000 features per frame (the walk keeps its state in LDS).
- * One search in flight per matcher handle (its scratch holds the candidate lists). */
+ * One search in flight per matcher handle (its scratch holds the candidate lists).  d_n_cur: NULL (n_cur is the exact count)
+ * or the current frame's count in DEVICE memory as the extractor wrote it -- n_cur is then only the capacity of the slab,
+ * and a caller chaining extraction and search never has to wait for the count (features at and beyond the count keep
+ * whatever d_cur_match / d_cur_taken held). */
 int orb_search_by_projection_device(OrbMatcher *m, const OrbKeyPoint *d_cur_kps, const uint8_t *d_cur_desc, int n_cur,
-                                    const OrbKeyPoint *d_last_kps, const uint8_t *d_last_desc, int n_last,
+                                    const int32_t *d_n_cur, const OrbKeyPoint *d_last_kps, const uint8_t *d_last_desc, int n_last,
                                     const uint8_t *d_last_flags, const double *d_last_xw, const double *Rcw9, const double *tcw3,
                                     double fx, double fy, double cx, double cy, const float *scale_factors, int nlevels,
                                     float min_x, float max_x, float min_y, float max_y, uint8_t *d_cur_taken, float th,
@@ -276,12 +279,54 @@ int ba_get_iteration_ms(BASolver *s, float *avg_ms, int32_t *n_launches, int32_t
 int ba_pose_optimization(BASolver *s, double *pose, const double *xw, const double *obs,
                          const double *inv_sigma2, int n, double fx, double fy, double cx, double cy,
                          uint8_t *outlier, int32_t *n_inliers);
+/* PoseOptimization of the correspondences a device-resident SearchByProjection produced: the pose problem of
+ * Optimizer::PoseOptimization(Frame*) (src/Optimizer.cpp:161-200) built on the device from the current frame's features j
+ * with d_cur_match[j] >= 0, in index order -- world point d_last_xw[3 * match], measurement = the keypoint position,
+ * information = inv_sigma2_levels[octave] -- and solved by the same kernel as ba_pose_optimization.  d_cur_kps[cap_cur] /
+ * d_n_cur as an extractor left them in device memory; d_pose7 in (initial estimate) / out; d_outlier[cap_cur] per CURRENT
+ * feature (0 where it has no correspondence); d_n_inliers, d_n_corr (may be NULL) out.  Everything d_* is device memory,
+ * inv_sigma2_levels a host array read before the call returns; enqueued on `stream` (NULL = the solver's), no copy, no
+ * wait.  Uses the solver's pose buffers: one pose call in flight per handle. */
+int ba_pose_optimization_matches_device(BASolver *s, const OrbKeyPoint *d_cur_kps, int cap_cur, const int32_t *d_n_cur,
+                                        const int32_t *d_cur_match, const double *d_last_xw, double *d_pose7,
+                                        const double *inv_sigma2_levels, int nlevels, double fx, double fy, double cx, double cy,
+                                        uint8_t *d_outlier, int32_t *d_n_inliers, int32_t *d_n_corr, void *stream);
 /* n_problems independent pose problems in one launch (Tracking calls PoseOptimization up to three times per
  * frame: src/Tracking.cpp:309,355,382).  Problem p owns edges [offsets[p], offsets[p+1]) of xw / obs /
  * inv_sigma2 / outlier; poses[7*n_problems] in/out; n_inliers[n_problems] out. */
 int ba_pose_optimization_batch(BASolver *s, double *poses, const double *xw, const double *obs,
                                const double *inv_sigma2, const int32_t *offsets, int n_problems, double fx, double fy,
                                double cx, double cy, uint8_t *outlier, int32_t *n_inliers);
+
+/* ---- One frame of Tracking::TrackWithMotionModel as ONE device chain (round 3) ----------------------------------------
+ * The reference's caller makes three calls per frame -- Frame(im, &extractor) (src/Frame.cpp:77), SearchByProjection
+ * (src/Tracking.cpp:344) and PoseOptimization (:355) -- each a host round trip through cv:: containers, and the drop-in
+ * classes keep that shape.  A caller that can take the three results together uses an OrbTracker: the image and the
+ * previous frame's map-point association go up in one copy, the extracted features STAY in device memory (they are the
+ * next call's "last frame"), projection / candidate scan / sequential walk / rotation histogram and the pose problem built
+ * from the matches follow on one stream without a wait, and keypoints, descriptors, match indices, outlier labels, pose and
+ * counts come back in one copy: one synchronisation per frame.  Same kernels, same arithmetic, same results as the three
+ * calls.  The tracker borrows the three handles (one frame in flight; do not use them concurrently from elsewhere).
+ *
+ * orb_tracker_track: gray/w/h/stride as orb_extract.  prev_flags[n_prev] / prev_xw[n_prev * 3]: the map-point association of
+ * the PREVIOUS frame's features (bit0 = holds a map point and is not an outlier, bit1 = the point has observations; world
+ * position read where bit0 is set); n_prev = 0 on the first frame (or after orb_tracker_reset): extraction only.  pose_pred7:
+ * the predicted pose (qw qx qy qz tx ty tz, world -> camera).  Image bounds as Frame::FindimageBound gives them.  Outputs:
+ * kps_out / desc_out / n_out as orb_extract (cap >= orb_max_keypoints of the extractor); cur_match[n] = index of the previous
+ * frame's feature whose map point the feature receives, or -1; outlier[n] = PoseOptimization's label of that
+ * correspondence; pose_out7; n_matches (SearchByProjection's count), n_inliers (PoseOptimization's return value).  The
+ * retry with a wider window when fewer than 20 matches are found (src/Tracking.cpp:347-351) is the caller's second call
+ * (orb_search_by_projection on the returned features): rare, and its inputs are in the caller's hands already.
+ * Keypoint positions are the measurements: frames are taken to be undistorted. */
+typedef struct OrbTracker OrbTracker;
+int orb_tracker_create(OrbExtractor *ext, OrbMatcher *mat, BASolver *sol, int device_id, OrbTracker **out);
+void orb_tracker_destroy(OrbTracker *t);
+int orb_tracker_reset(OrbTracker *t);
+int orb_tracker_track(OrbTracker *t, const uint8_t *gray, int w, int h, int stride, const uint8_t *prev_flags, const double *prev_xw,
+                      int n_prev, const double *pose_pred7, double fx, double fy, double cx, double cy, float min_x, float max_x,
+                      float min_y, float max_y, float th, int check_orientation, OrbKeyPoint *kps_out, uint8_t *desc_out, int cap,
+                      int32_t *n_out, int32_t *cur_match, uint8_t *outlier, double *pose_out7, int32_t *n_matches,
+                      int32_t *n_inliers);
 
 #ifdef __cplusplus
 }

@@ -9,3 +9,4 @@ from ._lib import KP_DTYPE, OrbError, build  # noqa: F401
 from .extractor import ORBextractor  # noqa: F401
 from .matcher import FrameFeatures, ORBmatcher  # noqa: F401
 from .optimizer import Optimizer  # noqa: F401
+from .tracker import Tracker  # noqa: F401

@@ -61,7 +61,7 @@ EXPORTS = [
     "orb_set_profiling", "orb_get_stage_ms", "orb_matcher_set_profiling", "orb_matcher_get_ms", "orb_matcher_get_stage_ms", "orb_features_in_area",
     "orb_descriptor_distance", "orb_compute_three_maxima", "orb_matcher_create", "orb_matcher_destroy",
     "orb_matcher_stream", "orb_matcher_synchronize", "orb_hamming_knn2", "orb_match_init",
-    "orb_match_batch_device", "orb_search_by_projection", "orb_search_by_projection_device", "orb_search_by_bow", "ba_create", "ba_destroy", "ba_solve", "ba_solve_batch", "ba_submit_batch", "ba_wait", "ba_set_profiling", "ba_get_iteration_ms",
+    "orb_match_batch_device", "orb_search_by_projection", "orb_search_by_projection_device", "orb_search_by_bow", "orb_tracker_create", "orb_tracker_destroy", "orb_tracker_reset", "orb_tracker_track", "ba_pose_optimization_matches_device", "ba_create", "ba_destroy", "ba_solve", "ba_solve_batch", "ba_submit_batch", "ba_wait", "ba_set_profiling", "ba_get_iteration_ms",
     "ba_pose_optimization", "ba_pose_optimization_batch",
 ]
 
@@ -159,9 +159,17 @@ def lib():
                                          vp, vp]
     L.orb_search_by_projection.argtypes = [vp, C.POINTER(OrbFrameView), C.POINTER(OrbFrameView), vp, vp, vp, vp, C.c_double,
                                            C.c_double, C.c_double, C.c_double, vp, i32, vp, f32, i32, vp, vp]
-    L.orb_search_by_projection_device.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, C.c_double, C.c_double, C.c_double,
+    L.orb_search_by_projection_device.argtypes = [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, C.c_double, C.c_double, C.c_double,
                                                   C.c_double, vp, i32, f32, f32, f32, f32, vp, f32, i32, vp, vp, vp]
     L.orb_search_by_bow.argtypes = [vp, C.POINTER(OrbFrameView), vp, C.POINTER(OrbFrameView), f32, i32, vp, vp]
+    L.orb_tracker_create.argtypes = [vp, vp, vp, i32, C.POINTER(vp)]
+    L.orb_tracker_destroy.argtypes = [vp]
+    L.orb_tracker_destroy.restype = None
+    L.orb_tracker_reset.argtypes = [vp]
+    L.orb_tracker_track.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, vp, C.c_double, C.c_double, C.c_double, C.c_double, f32, f32, f32,
+                                    f32, f32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
+    L.ba_pose_optimization_matches_device.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, i32, C.c_double, C.c_double, C.c_double,
+                                                      C.c_double, vp, vp, vp, vp]
     L.ba_create.argtypes = [i32, i32, i32, i32, i32, C.POINTER(vp)]
     L.ba_destroy.argtypes = [vp]
     L.ba_destroy.restype = None

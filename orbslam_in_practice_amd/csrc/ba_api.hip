@@ -4612,6 +4612,107 @@ extern "C" int ba_pose_optimization_batch(BASolver *s, double *poses, const doub
     return ORB_OK;
 }
 
+/* ---- PoseOptimization of the correspondences a device-resident SearchByProjection produced (round 3) -------------------
+ * The pose problem of Optimizer::PoseOptimization(Frame*) (src/Optimizer.cpp:131-261) built ON THE DEVICE: the current
+ * frame's features j with cur_match[j] >= 0, in index order (the order Frame's slots are walked in, :161-200), each with the
+ * world point of the matched last-frame feature, its keypoint position as the measurement and 1 / sigma^2 of its octave.
+ * k_po_gather compacts them (order preserving, ballot prefix) into the solver's pose buffers, k_pose_opt runs unchanged,
+ * k_po_scatter spreads the outlier labels back over the features.  Device pointers in and out, enqueued on `stream`,
+ * no copy, no wait: the last link of extract -> SearchByProjection -> PoseOptimization without a host round trip. */
+struct POLevels {
+    double inv_sigma2[64];
+};
+__global__ __launch_bounds__(1024) void k_po_gather(const OrbKeyPoint *kps, const int32_t *n_cur_dev, int cap, const int32_t *match,
+                                                     const double *last_xw, POLevels lv, int nlevels, double *xw, double *obs,
+                                                     double *info, int32_t *idx, int32_t *offs, uint8_t *outlier_full, int32_t *n_corr) {
+    __shared__ int s_wave[16];
+    __shared__ int s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = min(*n_cur_dev, cap);
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int j0 = 0; j0 < n; j0 += 1024) {
+        const int j = j0 + tid;
+        const int mi = j < n ? match[j] : -1;
+        if (j < n) outlier_full[j] = 0; /* (k_po_scatter2 sets the labels of the features that have a correspondence) */
+        const bool has = mi >= 0;
+        const uint64_t bal = __ballot(has);
+        if (lane == 0) s_wave[wave] = __popcll(bal);
+        __syncthreads();
+        int before = s_base;
+        for (int w2 = 0; w2 < wave; w2++) before += s_wave[w2];
+        if (has) {
+            const int slot = before + __popcll(bal & ((1ull << lane) - 1ull));
+            const OrbKeyPoint kp = kps[j];
+            xw[3 * slot] = last_xw[3 * (int64_t)mi];
+            xw[3 * slot + 1] = last_xw[3 * (int64_t)mi + 1];
+            xw[3 * slot + 2] = last_xw[3 * (int64_t)mi + 2];
+            obs[2 * slot] = (double)kp.x;
+            obs[2 * slot + 1] = (double)kp.y;
+            info[slot] = lv.inv_sigma2[(kp.octave >= 0 && kp.octave < nlevels) ? kp.octave : 0];
+            idx[slot] = j;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w2 = 0; w2 < 16; w2++) tot += s_wave[w2];
+            s_base += tot;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        offs[0] = 0;
+        offs[1] = s_base;
+        if (n_corr) *n_corr = s_base;
+    }
+}
+__global__ void k_po_scatter2(const int32_t *offs, const int32_t *idx, const uint8_t *out_compact, uint8_t *outlier_full) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < offs[1]) outlier_full[idx[i]] = out_compact[i];
+}
+
+extern "C" int ba_pose_optimization_matches_device(BASolver *s, const OrbKeyPoint *d_cur_kps, int cap_cur, const int32_t *d_n_cur,
+                                                   const int32_t *d_cur_match, const double *d_last_xw, double *d_pose7,
+                                                   const double *inv_sigma2_levels, int nlevels, double fx, double fy, double cx,
+                                                   double cy, uint8_t *d_outlier, int32_t *d_n_inliers, int32_t *d_n_corr,
+                                                   void *stream) {
+    if (!s || !d_cur_kps || cap_cur <= 0 || !d_n_cur || !d_cur_match || !d_last_xw || !d_pose7 || !inv_sigma2_levels || nlevels <= 0 ||
+        nlevels > 64 || !d_outlier || !d_n_inliers)
+        return ORB_E_INVALID;
+    BCHK(hipSetDevice(s->device));
+    hipStream_t st = stream ? (hipStream_t)stream : s->stream;
+    int rc;
+    const size_t n = (size_t)cap_cur;
+    /* scratch in the solver's pose buffers, sized for the slab capacity once (growing frees the old block: only while idle) */
+    if (n * 6 + 8 > s->pocapD || n * 2 + 16 > s->pocapB || n + 8 > s->pocapI) {
+        BCHK(hipStreamSynchronize(st));
+        BCHK(hipStreamSynchronize(s->stream));
+        if ((rc = ba_grow(s->poD, s->pocapD, n * 6 + 8))) return rc;
+        if ((rc = ba_grow(s->poB, s->pocapB, n * 2 + 16))) return rc;
+        if ((rc = ba_grow(s->poI, s->pocapI, n + 8))) return rc;
+    }
+    double *d_xw = s->poD, *d_obs = d_xw + n * 3, *d_info = d_obs + n * 2;
+    uint8_t *d_fl = s->poB, *d_out = s->poB + n + 8;
+    int32_t *d_offs = s->poI, *d_idx = s->poI + 4;
+    POLevels lv;
+    for (int l = 0; l < 64; l++) lv.inv_sigma2[l] = l < nlevels ? inv_sigma2_levels[l] : 0.0;
+    hipLaunchKernelGGL(k_po_gather, dim3(1), dim3(1024), 0, st, d_cur_kps, d_n_cur, cap_cur, d_cur_match, d_last_xw, lv, nlevels, d_xw, d_obs,
+                       d_info, d_idx, d_offs, d_outlier, d_n_corr);
+    int lds_edges = 0;
+    const size_t po_lds = (n * 49 + 15) & ~(size_t)15;
+    if (po_lds <= 96 * 1024) {
+        lds_edges = cap_cur;
+        static PerDeviceLdsLimit po_lim2;
+        BCHK(po_lim2.ensure((const void *)k_pose_opt, po_lds));
+    }
+    hipLaunchKernelGGL(k_pose_opt, dim3(1), dim3(PO_T), lds_edges ? po_lds : 0, st, d_pose7, (const double *)d_xw, (const double *)d_obs,
+                       (const double *)d_info, d_fl, d_out, (const int32_t *)d_offs, fx, fy, cx, cy, d_n_inliers, lds_edges, 0);
+    hipLaunchKernelGGL(k_po_scatter2, dim3((cap_cur + 255) / 256), dim3(256), 0, st, (const int32_t *)d_offs, (const int32_t *)d_idx,
+                       (const uint8_t *)d_out, d_outlier);
+    BCHK(hipGetLastError());
+    return ORB_OK;
+}
+
 extern "C" int ba_pose_optimization(BASolver *s, double *pose, const double *xw, const double *obs, const double *inv_sigma2,
                                     int n, double fx, double fy, double cx, double cy, uint8_t *outlier, int32_t *n_inliers) {
     if (!s || !pose || !n_inliers || n < 0 || (n > 0 && (!xw || !obs || !inv_sigma2 || !outlier))) return ORB_E_INVALID;

@@ -608,6 +608,7 @@ struct QueryArgs {
     const OrbKeyPoint *kps2;
     const uint8_t *desc2;
     int n2;
+    const int32_t *n2_dev; /* NULL, or the frame's feature count in device memory (then n2 above is only a bound) */
     const uint8_t *qdesc; /* [nq][32] */
     const float *qxyr;    /* [nq][3] */
     const int32_t *qlvl;  /* [nq][2] (minLevel, maxLevel) or NULL */
@@ -627,6 +628,7 @@ __global__ __launch_bounds__(256) void k_query_topk(QueryArgs A) {
        (distance, order) are unique, so the QK_TOP smallest of the slices' lists are the QK_TOP smallest overall. */
     const int ql = threadIdx.x / QK_SLICES, sl = threadIdx.x - ql * QK_SLICES;
     const int q = blockIdx.x * (256 / QK_SLICES) + ql;
+    const int n2 = A.n2_dev ? min(*A.n2_dev, A.n2) : A.n2;
     const float invW = (float)GRID_COLS / (A.max_x - A.min_x), invH = (float)GRID_ROWS / (A.max_y - A.min_y);
     uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float x = 0, y = 0, r = 0;
@@ -649,8 +651,8 @@ __global__ __launch_bounds__(256) void k_query_topk(QueryArgs A) {
     uint64_t bk[QK_TOP];
 #pragma unroll
     for (int k = 0; k < QK_TOP; k++) bk[k] = ~0ull;
-    for (int t0 = 0; t0 < A.n2; t0 += MK_TILE) {
-        const int nt = min(MK_TILE, A.n2 - t0);
+    for (int t0 = 0; t0 < n2; t0 += MK_TILE) {
+        const int nt = min(MK_TILE, n2 - t0);
         __syncthreads();
         for (int i = threadIdx.x; i < nt; i += 256) {
             const OrbKeyPoint kp = A.kps2[t0 + i];
@@ -1131,6 +1133,7 @@ struct N4WalkArgs {
     const OrbKeyPoint *kps2;         /* current frame: candidates */
     const uint8_t *desc2;
     int n2;
+    const int32_t *n2_dev;           /* NULL, or the current frame's count in device memory (n2 is then the bound the LDS layout uses) */
     const OrbKeyPoint *kps1;         /* last frame: queries */
     const uint8_t *desc1;
     int nq;
@@ -1142,12 +1145,13 @@ struct N4WalkArgs {
 };
 __global__ __launch_bounds__(64) void k_n4_walk(N4WalkArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char n4_smem[];
-    const int lane = threadIdx.x, n2 = A.n2, nq = A.nq;
-    int32_t *s_stamp = (int32_t *)n4_smem;     /* [n2] */
-    int32_t *s_match = s_stamp + n2;           /* [n2] */
-    int32_t *s_feat = s_match + n2;            /* [nq] accepted feature of query i, or -1 */
+    const int lane = threadIdx.x, nq = A.nq;
+    const int n2 = A.n2_dev ? min(*A.n2_dev, A.n2) : A.n2;
+    int32_t *s_stamp = (int32_t *)n4_smem;     /* [n2] (laid out for the bound A.n2) */
+    int32_t *s_match = s_stamp + A.n2;         /* [n2] */
+    int32_t *s_feat = s_match + A.n2;          /* [nq] accepted feature of query i, or -1 */
     uint8_t *s_taken = (uint8_t *)(s_feat + nq); /* [n2] */
-    uint8_t *s_bin = s_taken + n2;             /* [nq] */
+    uint8_t *s_bin = s_taken + A.n2;           /* [nq] */
     __shared__ int s_hist[HISTO_LENGTH];
     __shared__ int s_acc;
     for (int j = lane; j < n2; j += 64) {
@@ -1534,7 +1538,7 @@ extern "C" int orb_search_by_projection(OrbMatcher *m, const OrbFrameView *cur, 
  * scan, sequential walk and rotation histogram are three kernels on `stream`, nothing is copied and nothing waits.  The
  * scratch of the matcher handle holds the query parameters and candidate lists: one search in flight per handle. */
 extern "C" int orb_search_by_projection_device(OrbMatcher *m, const OrbKeyPoint *d_cur_kps, const uint8_t *d_cur_desc, int n_cur,
-                                               const OrbKeyPoint *d_last_kps, const uint8_t *d_last_desc, int n_last,
+                                               const int32_t *d_n_cur, const OrbKeyPoint *d_last_kps, const uint8_t *d_last_desc, int n_last,
                                                const uint8_t *d_last_flags, const double *d_last_xw, const double *Rcw9,
                                                const double *tcw3, double fx, double fy, double cx, double cy,
                                                const float *scale_factors, int nlevels, float min_x, float max_x, float min_y,
@@ -1566,6 +1570,7 @@ extern "C" int orb_search_by_projection_device(OrbMatcher *m, const OrbKeyPoint 
     A.kps2 = d_cur_kps;
     A.desc2 = d_cur_desc;
     A.n2 = n2;
+    A.n2_dev = d_n_cur;
     A.qdesc = d_last_desc;
     A.qxyr = (const float *)(S + o_q);
     A.qlvl = (const int32_t *)(S + o_lv);
@@ -1582,6 +1587,7 @@ extern "C" int orb_search_by_projection_device(OrbMatcher *m, const OrbKeyPoint 
     WA.kps2 = d_cur_kps;
     WA.desc2 = d_cur_desc;
     WA.n2 = n2;
+    WA.n2_dev = d_n_cur;
     WA.kps1 = d_last_kps;
     WA.desc1 = d_last_desc;
     WA.nq = nq;

@@ -123,13 +123,13 @@ class ORBmatcher:
 
     def search_by_projection_device(self, d_cur_kps, d_cur_desc, n_cur, d_last_kps, d_last_desc, n_last, d_last_flags, d_last_xw,
                                     Rcw, tcw, fx, fy, cx, cy, scale_factors, bounds, d_cur_taken, th, d_cur_match, d_n_matches,
-                                    stream=None):
+                                    stream=None, d_n_cur=None):
         """orb_search_by_projection_device: every d_* argument is a device pointer (int); enqueued on `stream`, returns
         at once -- projection, candidate scan, walk and rotation histogram on the device, no copy and no wait"""
         R = np.ascontiguousarray(Rcw, np.float64).reshape(9)
         t = np.ascontiguousarray(tcw, np.float64).reshape(3)
         sf = np.ascontiguousarray(scale_factors, np.float32)
-        check(self._L.orb_search_by_projection_device(self._m, d_cur_kps, d_cur_desc, int(n_cur), d_last_kps, d_last_desc, int(n_last),
+        check(self._L.orb_search_by_projection_device(self._m, d_cur_kps, d_cur_desc, int(n_cur), d_n_cur, d_last_kps, d_last_desc, int(n_last),
                                                       d_last_flags, d_last_xw, ptr(R), ptr(t), fx, fy, cx, cy, ptr(sf), len(sf),
                                                       bounds[0], bounds[1], bounds[2], bounds[3], d_cur_taken, float(th),
                                                       int(self.mbCheckOrientation), d_cur_match, d_n_matches, stream))

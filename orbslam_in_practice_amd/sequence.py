@@ -132,6 +132,23 @@ class GpuBackend:
         self.ext.close()
 
 
+class TrackerBackend(GpuBackend):
+    """the same calls, with the per-frame chain extract -> SearchByProjection -> PoseOptimization as ONE device chain
+    (orbslam_in_practice_amd/tracker.py, csrc/orb_track.hip): one synchronisation per frame instead of three"""
+    name = "gpu-tracker"
+
+    def __init__(self, nfeatures, w, h, device=0):
+        super().__init__(nfeatures, w, h, device)
+        self.tracker = self.oa.Tracker(self.ext, self.matcher, self.opt, device)
+
+    def track(self, img, last_flags, last_xw, pose_pred, K, th):
+        return self.tracker.track(img, last_flags, last_xw, pose_pred, K[0], K[1], K[2], K[3], self.bounds, th, True)
+
+    def close(self):
+        self.tracker.close()
+        super().close()
+
+
 # ---- the loop ------------------------------------------------------------------------------------------------------
 def run_sequence(backend, frames, K, pose0, kf_every=4, ba_window=5, th=15.0):
     """returns dict(poses [n, 7], n_matches [n], n_inliers [n], matches: list of int32 arrays, ba_runs, n_points)"""
@@ -154,8 +171,13 @@ def run_sequence(backend, frames, K, pose0, kf_every=4, ba_window=5, th=15.0):
             pid[i] = len(pts)
             pts.append(X[j])
 
+    fused = hasattr(backend, "track")   # a backend that runs a frame's three calls as one device chain
     # frame 0: pose given, every keypoint becomes a map point
-    kps, desc = backend.extract(frames[0])
+    if fused:
+        r0 = backend.track(frames[0], np.zeros(0, np.uint8), np.zeros((0, 3)), np.asarray(pose0, np.float64), K, th)
+        kps, desc = r0["kps"], r0["desc"]
+    else:
+        kps, desc = backend.extract(frames[0])
     pid = np.full(len(kps), -1, np.int64)
     poses[0] = pose0
     new_points(poses[0], kps, pid)
@@ -164,7 +186,6 @@ def run_sequence(backend, frames, K, pose0, kf_every=4, ba_window=5, th=15.0):
     all_matches.append(np.zeros(0, np.int32))
     velocity = None
     for k in range(1, n):
-        kps, desc = backend.extract(frames[k])
         # constant-velocity prediction (Tracking::TrackWithMotionModel)
         Rl, tl = quat_to_R(poses[k - 1][:4]), poses[k - 1][4:]
         if velocity is not None:
@@ -176,19 +197,29 @@ def run_sequence(backend, frames, K, pose0, kf_every=4, ba_window=5, th=15.0):
         has = last["pid"] >= 0
         if has.any():
             xw[has] = np.asarray([pts[i] for i in last["pid"][has]])
-        nm, m = backend.search_by_projection((kps, desc), (last["kps"], last["desc"]), flags, xw, Rp, tp, K, th)
-        if nm < 20:  # wider window, as Tracking does
+        pose_pred = np.concatenate([R_to_quat(Rp), tp])
+        res = None
+        if fused:
+            res = backend.track(frames[k], flags, xw, pose_pred, K, th)
+            kps, desc, nm, m = res["kps"], res["desc"], res["n_matches"], res["match"]
+        else:
+            kps, desc = backend.extract(frames[k])
+            nm, m = backend.search_by_projection((kps, desc), (last["kps"], last["desc"]), flags, xw, Rp, tp, K, th)
+        if nm < 20:  # wider window, as Tracking does (src/Tracking.cpp:347-351): through the separate calls in either case
             nm, m = backend.search_by_projection((kps, desc), (last["kps"], last["desc"]), flags, xw, Rp, tp, K, 2 * th)
+            res = None
         all_matches.append(m.copy())
         n_matches[k] = nm
         cur_idx = np.where(m >= 0)[0]
         pid = np.full(len(kps), -1, np.int64)
         pid[cur_idx] = last["pid"][m[cur_idx]]
-        Xc = np.asarray([pts[i] for i in pid[cur_idx]]).reshape(-1, 3)
-        obs = np.stack([kps["x"][cur_idx], kps["y"][cur_idx]], -1).astype(np.float64)
-        info = backend.inv_sigma2[kps["octave"][cur_idx]]
-        pose_pred = np.concatenate([R_to_quat(Rp), tp])
-        pose, outl, ninl = backend.pose_optimization(pose_pred, Xc, obs, info, K)
+        if res is not None:
+            pose, outl, ninl = res["pose"], res["outlier"][cur_idx], res["n_inliers"]
+        else:
+            Xc = np.asarray([pts[i] for i in pid[cur_idx]]).reshape(-1, 3)
+            obs = np.stack([kps["x"][cur_idx], kps["y"][cur_idx]], -1).astype(np.float64)
+            info = backend.inv_sigma2[kps["octave"][cur_idx]]
+            pose, outl, ninl = backend.pose_optimization(pose_pred, Xc, obs, info, K)
         poses[k] = pose
         n_inliers[k] = ninl
         pid[cur_idx[outl != 0]] = -1        # Tracking discards the outlier associations

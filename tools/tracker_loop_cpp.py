@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Build and run tests/cpp/tracker_main.cpp -- the per-frame chain extract -> SearchByProjection -> PoseOptimization through
+the one-round-trip entry point orb_tracker_track -- on the synthetic plane sequence.   python tools/tracker_loop_cpp.py [n]"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+from orbslam_in_practice_amd import sequence as sq  # noqa: E402
+
+exe = ge.build_cpp_loop("tracker_main")
+td = tempfile.mkdtemp()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 80
+frames, gt, K, _ = sq.make_plane_sequence(5, n)
+frames.tofile(td + "/f.raw")
+gt.astype(np.float64).tofile(td + "/gt.bin")
+for rep in range(3):
+    out = subprocess.run([exe, "640", "480", str(n), td + "/f.raw", td + "/gt.bin", *("%.17g" % v for v in K), td + "/out.bin"],
+                         capture_output=True, text=True)
+    print(out.stdout.strip().splitlines()[0] if out.stdout else "", out.stderr.strip()[-300:])
+rec = np.frombuffer(open(td + "/out.bin", "rb").read(), np.dtype([("pose", "<f8", 7), ("nm", "<i4"), ("inl", "<i4")]), n, 4)
+print("ATE %.4f m, mean matches %.0f, mean inliers %.0f" % (sq.ate_rmse(rec["pose"].copy(), gt), rec["nm"][1:].mean(), rec["inl"][1:].mean()))
