@@ -93,3 +93,37 @@ def test_tracker_loop_in_cpp_through_the_c_abi(tmp_path):
     import json
     j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert (n - 1) / j["track_secs"] > 300, j      # (1300-1370 frames/s measured)
+
+
+def test_tracker_edge_cases():
+    """no map points on the previous frame (nothing to match: the pose comes back untouched, as PoseOptimization does with
+    fewer than three correspondences), a wrong n_prev (refused), reset (the next frame is a first frame again), and a
+    second tracker on the same device beside the first"""
+    import orbslam_in_practice_amd as oa
+    from orbslam_in_practice_amd import sequence as sq
+    frames, gt, K, _ = sq.make_plane_sequence(5, 4)
+    be = sq.TrackerBackend(1000, 640, 480)
+    r0 = be.track(frames[0], np.zeros(0, np.uint8), np.zeros((0, 3)), gt[0], K, 15.0)
+    n0 = len(r0["kps"])
+    assert n0 > 900 and (r0["match"] == -1).all() and not r0["outlier"].any() and np.array_equal(r0["pose"], gt[0])
+    r1 = be.track(frames[1], np.zeros(n0, np.uint8), np.zeros((n0, 3)), gt[1], K, 15.0)          # no feature holds a map point
+    assert r1["n_matches"] == 0 and r1["n_inliers"] == 0 and (r1["match"] == -1).all() and not r1["outlier"].any()
+    q = gt[1] * (1 if gt[1][0] >= 0 else -1)
+    assert np.abs(r1["pose"] - q).max() < 1e-15                                                   # (normalised, otherwise untouched)
+    with pytest.raises(oa.OrbError) as ei:
+        be.track(frames[2], np.zeros(n0 + 5, np.uint8), np.zeros((n0 + 5, 3)), gt[2], K, 15.0)    # not the previous frame's count
+    assert ei.value.code == oa._lib.ORB_E_INVALID
+    be.tracker.reset()
+    r2 = be.track(frames[2], np.zeros(0, np.uint8), np.zeros((0, 3)), gt[2], K, 15.0)
+    assert r2["n_matches"] == 0 and len(r2["kps"]) > 900
+    # the chain continues from the reset frame: same result as a fresh tracker fed the same two frames
+    X2 = sq.backproject_to_plane(gt[2], K, np.stack([r2["kps"]["x"], r2["kps"]["y"]], -1).astype(np.float64))
+    fl = np.full(len(r2["kps"]), 3, np.uint8)
+    r3 = be.track(frames[3], fl, X2, gt[3], K, 15.0)
+    other = sq.TrackerBackend(1000, 640, 480)
+    other.track(frames[2], np.zeros(0, np.uint8), np.zeros((0, 3)), gt[2], K, 15.0)
+    s3 = other.track(frames[3], fl, X2, gt[3], K, 15.0)
+    assert r3["n_matches"] == s3["n_matches"] > 100 and np.array_equal(r3["match"], s3["match"]) and np.array_equal(r3["pose"], s3["pose"])
+    assert np.array_equal(r3["outlier"], s3["outlier"]) and r3["n_inliers"] == s3["n_inliers"]
+    other.close()
+    be.close()
