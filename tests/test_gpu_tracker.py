@@ -92,7 +92,7 @@ def test_tracker_loop_in_cpp_through_the_c_abi(tmp_path):
     assert np.abs(rec["pose"][:4] - ref["poses"]).max() < 1e-7
     import json
     j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert (n - 1) / j["track_secs"] > 300, j      # (1300-1370 frames/s measured)
+    assert (n - 1) / j["track_secs"] > 150, j      # a floor for one cold run (1300-1370 frames/s warm: bench.py single_stream.device_chain)
 
 
 def test_tracker_edge_cases():
