@@ -30,7 +30,7 @@ enum {
                              reference divides by zero there, src/ORBextractor.cpp:493-495)           */
     ORB_E_STOPPED = -6,   /* ba_solve: *stop became true before the first iteration                    */
     ORB_E_RESERVED_7 = -7, /* retired (was ORB_E_SINGULAR in round 1): never returned, never reused        */
-    ORB_E_BUSY = -8       /* ba_submit_batch: two batches already in flight (call ba_wait first)       */
+    ORB_E_BUSY = -8       /* ba_submit_batch: all three batch slots in flight (call ba_wait first)     */
 };
 
 const char *orb_last_error(void);
@@ -260,8 +260,9 @@ int ba_solve(BASolver *s, const BAProblem *p, BAResult *r);
 int ba_solve_batch(BASolver *s, const BAProblem *p, BAResult *r, int n);
 /* The same in two halves, for a steady stream of batches: ba_submit_batch stages the batch on the host and enqueues
  * its uploads, kernels and download; ba_wait blocks until the OLDEST submitted batch has finished and fills its
- * BAResult array.  Up to two batches may be in flight, so the host side of batch k+1 and the download of batch k-1
- * overlap the kernels of batch k.  p / r and everything they point to must stay valid until the matching ba_wait.
+ * BAResult array.  Up to THREE batches may be in flight (each slot has its own pinned and device buffers): the host side of
+ * the next batch and the download of the previous one overlap the kernels of the running one, and the device queue always
+ * holds a staged batch beyond it.  A fourth ba_submit_batch without a ba_wait returns ORB_E_BUSY.  p / r and everything they point to must stay valid until the matching ba_wait.
  * A batch that carries a stop flag has to be polled between iterations and runs to completion inside submit. */
 int ba_submit_batch(BASolver *s, const BAProblem *p, BAResult *r, int n);
 int ba_wait(BASolver *s);

@@ -3535,6 +3535,10 @@ struct BAJob {
     double t_start = 0, t_staged = 0, t_enqueued = 0;
 };
 
+/* batches in flight through ba_submit_batch / ba_wait: each slot has its own pinned staging and device buffers.  Two slots
+   overlap the host side of batch k+1 with the kernels of batch k; with three the device queue always holds a staged batch
+   beyond the running one, so a slow staging pass (a box with less CPU) no longer shows as an idle device between batches. */
+#define BA_SLOTS 3
 struct BASolver {
     int device = 0;
     hipStream_t stream = nullptr;   /* kernels */
@@ -3542,7 +3546,7 @@ struct BASolver {
     hipStream_t copy_out = nullptr; /* downloads of the PREVIOUS batch */
     int max_cams, max_points, max_obs, max_batch;
     int cu_count = 256;
-    BAJob job[2];
+    BAJob job[BA_SLOTS];
     int next_slot = 0, oldest_slot = 0, in_flight = 0;
     std::vector<BAPiece> pieces;
     /* Optimizer::PoseOptimization has its own small buffers: Tracking may call it while a BA batch is in flight */
@@ -3577,7 +3581,7 @@ extern "C" int ba_create(int max_cams, int max_points, int max_obs, int max_batc
     bool ok = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&s->copy_in, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&s->copy_out, hipStreamNonBlocking) == hipSuccess;
-    for (int j = 0; j < 2 && ok; j++)
+    for (int j = 0; j < BA_SLOTS && ok; j++)
         ok = hipEventCreateWithFlags(&s->job[j].uploaded, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&s->job[j].solved, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&s->job[j].downloaded, hipEventDisableTiming) == hipSuccess;
@@ -4198,15 +4202,15 @@ static int ba_check_batch(BASolver *s, const BAProblem *probs, BAResult *res, in
 extern "C" int ba_submit_batch(BASolver *s, const BAProblem *probs, BAResult *res, int nwin) {
     int rc = ba_check_batch(s, probs, res, nwin);
     if (rc) return rc;
-    if (s->in_flight >= 2) {
-        b_err = "ba_submit_batch: two batches already in flight, call ba_wait first";
+    if (s->in_flight >= BA_SLOTS) {
+        b_err = "ba_submit_batch: every batch slot is in flight, call ba_wait first";
         return ORB_E_BUSY;
     }
     BCHK(hipSetDevice(s->device));
     BAJob &J = s->job[s->next_slot];
     if ((rc = ba_stage(s, J, probs, res, nwin))) return rc;
     if ((rc = ba_enqueue(s, J))) return rc;
-    s->next_slot ^= 1;
+    s->next_slot = (s->next_slot + 1) % BA_SLOTS;
     s->in_flight++;
     return ORB_OK;
 }
@@ -4215,7 +4219,7 @@ extern "C" int ba_wait(BASolver *s) {
     if (!s) return ORB_E_INVALID;
     if (s->in_flight <= 0) return ORB_OK;
     BAJob &J = s->job[s->oldest_slot]; /* the oldest batch is retired whatever happens below: callers that mirror */
-    s->oldest_slot ^= 1;               /* the queue (optimizer.py) pop their entry before looking at the status   */
+    s->oldest_slot = (s->oldest_slot + 1) % BA_SLOTS; /* the queue (optimizer.py) pop their entry before looking at the status */
     s->in_flight--;
     BCHK(hipSetDevice(s->device));
     return ba_finish(s, J);

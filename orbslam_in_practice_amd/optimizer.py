@@ -103,7 +103,7 @@ class Optimizer:
         return self._collect(job)
 
     def submit_batch(self, windows, rounds, robust=True, chi2_threshold=CHI2_2D, drop_robust_after=0):
-        """ba_submit_batch: stage + enqueue, returns at once (two batches may be in flight); pair with wait()"""
+        """ba_submit_batch: stage + enqueue, returns at once (three batches may be in flight); pair with wait()"""
         job = self._prepare(windows, rounds, robust, chi2_threshold, drop_robust_after, None)
         check(self._L.ba_submit_batch(self._s, job["Ps"], job["Rs"], job["n"]))
         self._jobs.append(job)   # keeps every buffer the C side points into alive until wait()

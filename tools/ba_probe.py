@@ -29,14 +29,20 @@ for nu in [int(a) for a in sys.argv[1:]] or [4, 32]:
     print("unique %d batch %d: call %.1f ms, kernel launches %d x %.2f ms = %.1f ms, team %d, lin_solves min/mean/max %d/%.2f/%d, E min/max %d/%d"
           % (nu, batch, dt * 1e3, nl, ms, nl * ms, team, ls.min(), ls.mean(), ls.max(), E.min(), E.max()))
     reps = int(os.environ.get("STREAM", "0"))
-    if reps:  # a stream of batches through submit / wait (two in flight): windows/s with staging and copies overlapped
+    if reps:  # a stream of batches through submit / wait (DEPTH in flight): windows/s with staging and copies overlapped
+        depth = int(os.environ.get("DEPTH", "3"))
         opt.set_profiling(False)
-        opt.submit_batch(wins, (5, 10))
+        pending = 0
+        for _ in range(depth - 1):
+            opt.submit_batch(wins, (5, 10))
+            pending += 1
         t0 = time.perf_counter()
         for _ in range(reps):
             opt.submit_batch(wins, (5, 10))
             opt.wait()
         dt = time.perf_counter() - t0
-        opt.wait()
-        print("  streamed: %d batches of %d in %.1f ms = %.0f windows/s" % (reps, batch, dt * 1e3, reps * batch / dt))
+        while pending:
+            opt.wait()
+            pending -= 1
+        print("  streamed (%d in flight): %d batches of %d in %.1f ms = %.0f windows/s" % (depth, reps, batch, dt * 1e3, reps * batch / dt))
     opt.close()
