@@ -388,7 +388,7 @@ def main():
     ap.add_argument("--split", type=int, default=2, help="1..4 launch lanes: equal parts of a batch on separate stream pairs")
     ap.add_argument("--ba-windows", type=int, default=256, help="local-BA windows per GPU per batch (0 = skip)")
     ap.add_argument("--ba-size", default="100x5000", help="keyframes x points of a window (configs[2] = 50x2000)")
-    ap.add_argument("--ba-reps", type=int, default=24, help="batches in the timed BA stream")
+    ap.add_argument("--ba-reps", type=int, default=48, help="batches in the timed BA stream (the pipeline fill of three slots weighs 1/16)")
     ap.add_argument("--sequence-frames", type=int, default=40, help="frames of the one-stream-per-GPU tracking loop (0 = skip)")
     args = ap.parse_args()
     W, H = (int(v) for v in args.size.lower().split("x"))
