@@ -471,6 +471,7 @@ __device__ __forceinline__ double team_max(double v, BAShared &s, BATeam &t) {
 /* errors of all active edges at (poses, pts) -> err ; returns robust chi2 (activeRobustChi2) */
 __device__ double eval_chi2_partial(const BAWin &w, double *D, const int32_t *I, const uint8_t *B, int64_t poses, int64_t pts,
                                     int64_t err, const BATeam &t) {
+    constexpr bool STORE = true; /* (the fused / team kernel reads the err array back; the phase kernels' twin, ba_ph_chi2_part, may not store) */
     /* two edges per step, every index / flag / observation load issued before the first dependent gather and none of
        them behind the "inactive edge" branch (inactive edges are computed and discarded): a quarter of the dependent
        memory round trips of the plain loop.  Same per-thread summation order (e, e + T, e + 2T, ...). */
@@ -488,15 +489,19 @@ __device__ double eval_chi2_partial(const BAWin &w, double *D, const int32_t *I,
         project_err(D + poses + (int64_t)cB * 7, D + pts + (int64_t)pB * 3, D + w.obs + (int64_t)eB * 2, w.fx, w.fy, w.cx, w.cy, erB,
                     pc);
         if (fA & 1) {
-            D[err + (int64_t)eA * 2] = erA[0];
-            D[err + (int64_t)eA * 2 + 1] = erA[1];
+            if (STORE) {
+                D[err + (int64_t)eA * 2] = erA[0];
+                D[err + (int64_t)eA * 2 + 1] = erA[1];
+            }
             double c = (erA[0] * erA[0] + erA[1] * erA[1]) * iA;
             if (fA & 2) c = huber_rho0(c, w.delta);
             acc += c;
         }
         if (vB && (fB & 1)) {
-            D[err + (int64_t)eB * 2] = erB[0];
-            D[err + (int64_t)eB * 2 + 1] = erB[1];
+            if (STORE) {
+                D[err + (int64_t)eB * 2] = erB[0];
+                D[err + (int64_t)eB * 2 + 1] = erB[1];
+            }
             double c = (erB[0] * erB[0] + erB[1] * erB[1]) * iB;
             if (fB & 2) c = huber_rho0(c, w.delta);
             acc += c;
@@ -1669,7 +1674,13 @@ __device__ __noinline__ bool ba_pcg_global(const BAWin &w, double *D, const int3
  * wavefronts) of which this thread is gtid (this wavefront gwave). ---- */
 /* buildSystem: Hll, bl (thread per point; W is written by the camera pass, which has the same Jacobians in hand and
    stores whole 144-byte records instead of 18 doubles strided over the lanes) */
+/* FROM_OBS (the phase-kernel path): the edge's error is recomputed from its observation and the projection this pass has in
+   hand anyway -- same expression as project_err, hence the same bits -- instead of being read from the err array; nothing
+   reads that array then, so the trial pass does not write it and an accepted trial does not copy it (345 MB per trial and
+   256 windows: a seventh of the batch's HBM traffic). */
+template <bool FROM_OBS = false>
 __device__ __forceinline__ void ba_phase_hll(const BAWin &w, double *D, const int32_t *I, const uint8_t *B, int gtid, int gthreads) {
+    const int64_t esrc = FROM_OBS ? w.obs : w.err;
     for (int p = gtid; p < w.Np; p += gthreads) {
         double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
         const int e0 = I[w.pt_start + p], e1 = I[w.pt_start + p + 1];
@@ -1681,19 +1692,20 @@ __device__ __forceinline__ void ba_phase_hll(const BAWin &w, double *D, const in
         if (e0 < e1) {
             fn = B[w.flags + e0];
             cn = I[w.cam + e0];
-            er0n = D[w.err + (int64_t)e0 * 2];
-            er1n = D[w.err + (int64_t)e0 * 2 + 1];
+            er0n = D[esrc + (int64_t)e0 * 2];
+            er1n = D[esrc + (int64_t)e0 * 2 + 1];
             infon = D[w.info + e0];
         }
         for (int e = e0; e < e1; e++) {
             const uint8_t f = fn;
             const int c = cn;
-            const double er0 = er0n, er1 = er1n, info = infon;
+            double er0 = er0n, er1 = er1n;
+            const double info = infon;
             if (e + 1 < e1) {
                 fn = B[w.flags + e + 1];
                 cn = I[w.cam + e + 1];
-                er0n = D[w.err + (int64_t)(e + 1) * 2];
-                er1n = D[w.err + (int64_t)(e + 1) * 2 + 1];
+                er0n = D[esrc + (int64_t)(e + 1) * 2];
+                er1n = D[esrc + (int64_t)(e + 1) * 2 + 1];
                 infon = D[w.info + e + 1];
             }
             if (!(f & 1)) continue;
@@ -1704,6 +1716,10 @@ __device__ __forceinline__ void ba_phase_hll(const BAWin &w, double *D, const in
             pc[0] = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + pose[4];
             pc[1] = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + pose[5];
             pc[2] = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + pose[6];
+            if (FROM_OBS) { /* (er0, er1) held the observation */
+                er0 = er0 - (pc[0] / pc[2] * w.fx + w.cx);
+                er1 = er1 - (pc[1] / pc[2] * w.fy + w.cy);
+            }
             double Ji[6], Jj[12];
             jacobians(pose, pc, w.fx, w.fy, Ji, Jj);
             double wgt = info, r0 = -info * er0, r1 = -info * er1;
@@ -1724,7 +1740,7 @@ __device__ __forceinline__ void ba_phase_hll(const BAWin &w, double *D, const in
 }
 /* Hpp, bp, W = Hpl: one wavefront per free camera, lanes over its edges, shuffle reduction.  (The W record of an edge of a
    FIXED camera is never read: the Schur lists, g and the back-substitution only follow free cameras.) */
-template <bool COMPACT = false>
+template <bool COMPACT = false, bool FROM_OBS = false>
 __device__ __forceinline__ void ba_phase_hpp(const BAWin &w, double *D, const int32_t *I, const uint8_t *B, int gwave, int gwaves, int lane) {
     for (int c = gwave; c < w.Nc; c += gwaves) {
         const int sl = I[w.slot + c];
@@ -1758,7 +1774,11 @@ __device__ __forceinline__ void ba_phase_hpp(const BAWin &w, double *D, const in
             pc[2] = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + pose[6];
             double Ji[6], Jj[12];
             jacobians(pose, pc, w.fx, w.fy, Ji, Jj);
-            const double er0 = D[w.err + (int64_t)e * 2], er1 = D[w.err + (int64_t)e * 2 + 1];
+            double er0 = D[(FROM_OBS ? w.obs : w.err) + (int64_t)e * 2], er1 = D[(FROM_OBS ? w.obs : w.err) + (int64_t)e * 2 + 1];
+            if (FROM_OBS) { /* the observation: the error from the projection in hand (ba_phase_hll has the note) */
+                er0 = er0 - (pc[0] / pc[2] * w.fx + w.cx);
+                er1 = er1 - (pc[1] / pc[2] * w.fy + w.cy);
+            }
             const double info = D[w.info + e];
             double wgt = info, r0 = -info * er0, r1 = -info * er1;
             if (f & 2) {
@@ -1971,10 +1991,12 @@ __device__ __forceinline__ void ba_phase_zero2(const BAWin &w, double *D, int gt
     for (int i = gtid; i < w.Ncf * 6; i += gthreads) D[w.g2 + i] = 0.0;
 }
 /* accepted trial: it becomes the estimate */
+template <bool COPY_ERR = true>
 __device__ __forceinline__ void ba_phase_accept(const BAWin &w, double *D, int gtid, int gthreads) {
     for (int i = gtid; i < w.Nc * 7; i += gthreads) D[w.poses + i] = D[w.poses_t + i];
     for (int i = gtid; i < w.Np * 3; i += gthreads) D[w.pts + i] = D[w.pts_t + i];
-    for (int i = gtid; i < w.E * 2; i += gthreads) D[w.err + i] = D[w.err_t + i];
+    if (COPY_ERR)
+        for (int i = gtid; i < w.E * 2; i += gthreads) D[w.err + i] = D[w.err_t + i];
 }
 
 /* n_iters LM iterations (OptimizationAlgorithmLevenberg::solve) for every window of the batch.  A whole optimize()
@@ -2438,7 +2460,7 @@ template <class SH> __device__ __forceinline__ void ba_ph_update(const BAWin &w,
         alpha = fmin(alpha, 2. / 3.);
         lambda *= fmax(1. / 3., alpha);
         ni = 2;
-        ba_phase_accept(w, D, threadIdx.x, BA_T);
+        ba_phase_accept<false>(w, D, threadIdx.x, BA_T);
     } else {
         lambda *= ni;
         ni *= 2;
@@ -2519,6 +2541,7 @@ template <class SH> __device__ __forceinline__ double block_sum_n(double v, SH &
 }
 /* errors + robust chi2 of this part's edges at (poses, pts): the same two-edges-per-step loop as eval_chi2_partial,
    for a workgroup of BA_PH_T threads */
+template <bool STORE = true>
 __device__ __forceinline__ double ba_ph_chi2_part(const BAWin &w, double *D, const int32_t *I, const uint8_t *B, int64_t poses, int64_t pts,
                                                   int64_t err, int gtid, int gthreads) {
     double acc = 0;
@@ -2532,15 +2555,19 @@ __device__ __forceinline__ double ba_ph_chi2_part(const BAWin &w, double *D, con
         project_err(D + poses + (int64_t)cA * 7, D + pts + (int64_t)pA * 3, D + w.obs + (int64_t)eA * 2, w.fx, w.fy, w.cx, w.cy, erA, pc);
         project_err(D + poses + (int64_t)cB * 7, D + pts + (int64_t)pB * 3, D + w.obs + (int64_t)eB * 2, w.fx, w.fy, w.cx, w.cy, erB, pc);
         if (fA & 1) {
-            D[err + (int64_t)eA * 2] = erA[0];
-            D[err + (int64_t)eA * 2 + 1] = erA[1];
+            if (STORE) {
+                D[err + (int64_t)eA * 2] = erA[0];
+                D[err + (int64_t)eA * 2 + 1] = erA[1];
+            }
             double c = (erA[0] * erA[0] + erA[1] * erA[1]) * iA;
             if (fA & 2) c = huber_rho0(c, w.delta);
             acc += c;
         }
         if (vB && (fB & 1)) {
-            D[err + (int64_t)eB * 2] = erB[0];
-            D[err + (int64_t)eB * 2 + 1] = erB[1];
+            if (STORE) {
+                D[err + (int64_t)eB * 2] = erB[0];
+                D[err + (int64_t)eB * 2 + 1] = erB[1];
+            }
             double c = (erB[0] * erB[0] + erB[1] * erB[1]) * iB;
             if (fB & 2) c = huber_rho0(c, w.delta);
             acc += c;
@@ -2554,22 +2581,22 @@ __global__ __launch_bounds__(BA_PH_T) void k_ba_ph_chi2(BABufs bufs) {
     BA_PH_WINDOW_COPY
     const int parts = ba_ph_parts_e(w.E);
     if (ph != 0.0 || D[w.st + ST_HAVECHI] != 0.0 || (int)blockIdx.y >= parts) return;
-    const double v = block_sum_n(ba_ph_chi2_part(w, D, I, B, w.poses, w.pts, w.err, blockIdx.y * BA_PH_T + threadIdx.x, parts * BA_PH_T), s, BA_PH_T / 64);
+    const double v = block_sum_n(ba_ph_chi2_part<false>(w, D, I, B, w.poses, w.pts, w.err, blockIdx.y * BA_PH_T + threadIdx.x, parts * BA_PH_T), s, BA_PH_T / 64);
     if (threadIdx.x == 0) D[w.gred + PH_RED_CHI + blockIdx.y] = v;
 }
 __global__ __launch_bounds__(BA_PH_T) void k_ba_ph_hll(BABufs bufs) {
     BA_PH_WINDOW_COPY
     if (ph != 0.0) return;
-    ba_phase_hll(w, D, I, B, blockIdx.y * BA_PH_T + threadIdx.x, gridDim.y * BA_PH_T);
+    ba_phase_hll<true>(w, D, I, B, blockIdx.y * BA_PH_T + threadIdx.x, gridDim.y * BA_PH_T);
 }
 __global__ __launch_bounds__(BA_PH_T) void k_ba_ph_hpp(BABufs bufs) { /* one wavefront per camera */
     BA_PH_WINDOW_COPY
     if (ph != 0.0) return;
     const int gw = blockIdx.y * (BA_PH_T / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), gws = gridDim.y * (BA_PH_T / 64);
     if (w.nchunks > 0)
-        ba_phase_hpp<true>(w, D, I, B, gw, gws, threadIdx.x & 63);  /* point chunks: 32-byte edge records */
+        ba_phase_hpp<true, true>(w, D, I, B, gw, gws, threadIdx.x & 63);  /* point chunks: 32-byte edge records */
     else
-        ba_phase_hpp<false>(w, D, I, B, gw, gws, threadIdx.x & 63); /* per-block lists (long tracks): W itself */
+        ba_phase_hpp<false, true>(w, D, I, B, gw, gws, threadIdx.x & 63); /* per-block lists (long tracks): W itself */
 }
 /* single workgroup per window: the current chi2 from its partial sums, computeLambdaInit on the first iteration of a
    round, trial counter */
@@ -2887,7 +2914,7 @@ __global__ __launch_bounds__(BA_PH_T) void k_ba_ph_trial(BABufs bufs) {
     BA_PH_WINDOW_COPY
     const int parts = ba_ph_parts_e(w.E);
     if (ph == 2.0 || (int)blockIdx.y >= parts) return;
-    const double v = block_sum_n(ba_ph_chi2_part(w, D, I, B, w.poses_t, w.pts_t, w.err_t, blockIdx.y * BA_PH_T + threadIdx.x, parts * BA_PH_T), s, BA_PH_T / 64);
+    const double v = block_sum_n(ba_ph_chi2_part<false>(w, D, I, B, w.poses_t, w.pts_t, w.err_t, blockIdx.y * BA_PH_T + threadIdx.x, parts * BA_PH_T), s, BA_PH_T / 64);
     if (threadIdx.x == 0) D[w.gred + PH_RED_TRIAL + blockIdx.y] = v;
 }
 /* gain ratio and g2o's accept / reject bookkeeping: one thread per window */
@@ -2943,7 +2970,7 @@ __global__ __launch_bounds__(BA_PH_T) void k_ba_ph_accept(BABufs bufs, int trial
     const BAWin &w = bufs.wins[blockIdx.x];
     double *D = bufs.D;
     if (D[w.st + ST_ACCEPT] != (double)(trial_seq + 1)) return;
-    ba_phase_accept(w, D, blockIdx.y * BA_PH_T + threadIdx.x, gridDim.y * BA_PH_T);
+    ba_phase_accept<false>(w, D, blockIdx.y * BA_PH_T + threadIdx.x, gridDim.y * BA_PH_T);
 }
 /* whatever is left of the round, in one workgroup per window (normally nothing: every window is at ST_PH == 2) */
 __global__ __launch_bounds__(BA_T) void k_ba_ph_finish(BABufs bufs, int band) {
@@ -2961,11 +2988,11 @@ __global__ __launch_bounds__(BA_T) void k_ba_ph_finish(BABufs bufs, int band) {
         if (ph == 0.0) {
             if (D[w.st + ST_HAVECHI] == 0.0) ba_ph_chi2(w, D, I, B, s);
             __syncthreads();
-            ba_phase_hll(w, D, I, B, threadIdx.x, BA_T);
+            ba_phase_hll<true>(w, D, I, B, threadIdx.x, BA_T);
             if (w.nchunks > 0)
-                ba_phase_hpp<true>(w, D, I, B, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), BA_W, threadIdx.x & 63);
+                ba_phase_hpp<true, true>(w, D, I, B, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), BA_W, threadIdx.x & 63);
             else
-                ba_phase_hpp<false>(w, D, I, B, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), BA_W, threadIdx.x & 63);
+                ba_phase_hpp<false, true>(w, D, I, B, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), BA_W, threadIdx.x & 63);
             __syncthreads();
         }
         ba_ph_dinv(w, D, I, s);
