@@ -1862,7 +1862,10 @@ __device__ __forceinline__ double ba_phase_lambda0(const BAWin &w, const double 
 /* PARTS: the two-part Schur pass starts the blocks it touches itself (BA_BLK_FIRST); only the others are written here */
 template <bool PARTS = false>
 __device__ __forceinline__ void ba_phase_dinv(const BAWin &w, double *D, const int32_t *I, double lambda, int gtid, int gthreads) {
-    for (int p = gtid; p < w.Np; p += gthreads) {
+    /* PARTS (a chunked window on the phase-kernel path): Dinv and tv are not formed at all -- the Schur pass works with the
+       factor U of ba_phase_ufactor (Dinv = U U^T, u = U^T bl) and the back-substitution applies U (U^T c) -- 96 bytes per
+       point and trial that were written and read for nothing */
+    for (int p = gtid; p < (PARTS ? 0 : w.Np); p += gthreads) {
         double Dm[9];
         for (int i = 0; i < 9; i++) Dm[i] = D[w.Hll + (int64_t)p * 9 + i];
         Dm[0] += lambda;
@@ -1927,9 +1930,20 @@ __device__ __forceinline__ double ba_phase_backsub(const BAWin &w, double *D, co
                     for (int a = 0; a < 6; a++) cl[bb] -= We[a * 3 + bb] * xc[a];
             }
         }
-        const double *Iv = D + w.Dinv + (int64_t)p * 9;
+        double vv[3];
+        if (COMPACT) { /* Dinv c = U (U^T c), U upper triangular (ba_phase_ufactor): the window keeps no Dinv */
+            const double *U = D + w.Uf + (int64_t)p * 6;
+            const double u0 = U[0], u1 = U[1], u2 = U[2], u3 = U[3], u4 = U[4], u5 = U[5];
+            const double t0 = u0 * cl[0], t1 = u1 * cl[0] + u3 * cl[1], t2 = u2 * cl[0] + u4 * cl[1] + u5 * cl[2];
+            vv[0] = u0 * t0 + u1 * t1 + u2 * t2;
+            vv[1] = u3 * t1 + u4 * t2;
+            vv[2] = u5 * t2;
+        } else {
+            const double *Iv = D + w.Dinv + (int64_t)p * 9;
+            for (int a = 0; a < 3; a++) vv[a] = Iv[a * 3] * cl[0] + Iv[a * 3 + 1] * cl[1] + Iv[a * 3 + 2] * cl[2];
+        }
         for (int a = 0; a < 3; a++) {
-            const double v = ok2 ? (Iv[a * 3] * cl[0] + Iv[a * 3 + 1] * cl[1] + Iv[a * 3 + 2] * cl[2]) : 0.0;
+            const double v = ok2 ? vv[a] : 0.0;
             D[w.pts_t + (int64_t)p * 3 + a] = D[w.pts + (int64_t)p * 3 + a] + v;
             scale_loc += v * (lambda * v + D[w.bl + (int64_t)p * 3 + a]);
         }
