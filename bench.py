@@ -41,6 +41,7 @@ W, H = 640, 480
 NFEATURES, SCALE, NLEVELS, INI_TH, MIN_TH = 1000, 1.2, 8, 20, 7
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 VALU_PEAK_GINST = 1024 * 1.2  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles at 2.4 GHz
+MFMA_I8_PEAK_TOPS = 5000.0  # dense i8 MFMA: twice the ~2.5 PFLOP/s bf16 peak (MI355X_MICROARCH.md, Matrix cores)
 
 
 def algorithmic_bytes_per_frame(level_sizes, n_kp):
@@ -61,7 +62,7 @@ def algorithmic_bytes_per_frame(level_sizes, n_kp):
 SINGLE_KERNEL_STAGES = ("fast", "quadtree", "blur", "describe", "match_knn", "match_resolve")
 # stage -> the kernel symbol(s) behind it (csrc/*.hip) and the source file the stage's PMC figures depend on
 STAGE_KERNEL = {"pyramid": "k_copy_level0 + k_resize x7", "fast": "k_fast_cells_wave", "quadtree": "k_quadtree",
-                "blur": "k_blur", "describe": "k_describe", "match_knn": "k_match_knn", "match_resolve": "k_match_init"}
+                "blur": "k_blur", "describe": "k_describe", "match_knn": "k_match_knn_mfma", "match_resolve": "k_match_init"}
 STAGE_SOURCE = {"pyramid": "orb_pyramid.hip", "blur": "orb_pyramid.hip", "fast": "orb_fast.hip", "quadtree": "orb_quadtree.hip",
                 "describe": "orb_describe.hip", "match_knn": "orb_match.hip", "match_resolve": "orb_match.hip",
                 "ba_iteration": "ba_api.hip"}
@@ -598,6 +599,14 @@ def main():
                 ginst = tj[vk] * Bh / float(tj.get("_batch", Bh)) / 1e9
                 r["valu"] = {"source": traffic_src, "insts_per_launch": int(ginst * 1e9), "achieved_ginst_s": round(ginst / (stage_ms[k] * 1e-3), 1),
                              "peak_ginst_s": VALU_PEAK_GINST, "frac": round(ginst / (stage_ms[k] * 1e-3) / VALU_PEAK_GINST, 4)}
+            if k == "match_knn":
+                # the all-pairs Hamming product on the matrix cores (v_mfma_i32_32x32x32_i8): 2 x 256 integer ops per
+                # (query, F2 keypoint) pair of 32-row tiles; priced against the dense i8 peak (2 x the bf16 peak)
+                tops = 2.0 * 256.0 * (32.0 * np.ceil(n_kp / 32.0)) ** 2 * Bh / (stage_ms[k] * 1e-3) / 1e12
+                r["mfma"] = {"dtype": "i8", "achieved": round(tops, 2), "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
+                             "frac": round(tops / MFMA_I8_PEAK_TOPS, 5),
+                             "note": "in-flight interval beside the other lane's kernels; the kernel is bound by looking at the "
+                                     "results (3 VALU instructions per 64 distances), not by the products"}
             return r
         pipe_bytes = sum(ab.values()) * world * B * S * args.steps
         pipe = pipe_bytes / elapsed / 1e9

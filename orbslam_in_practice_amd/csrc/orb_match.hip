@@ -266,6 +266,234 @@ __global__ __launch_bounds__(256) void k_match_knn(MatchArgs A) {
     }
 }
 
+/* PHASE 1 on the matrix cores (the KEY32 case).  All-pairs Hamming distance IS a matrix product: with the F2
+ * descriptor bits t_k in {0, 1} and the query bits as q'_k = 1 - 2 q_k in {+1, -1},
+ *       sum_k t_k q'_k = popc(t) - 2 popc(t & q)   ==>   d(t, q) = popc(t ^ q) = popc(q) + sum_k t_k q'_k
+ * so one v_mfma_i32_32x32x32_i8 chain over K = 256 gives 32 x 32 exact distances (minus a per-query constant) for
+ * 8 x 2 operand registers, against 16 VALU instructions PER PAIR for xor + popcount -- the scan this replaces was a
+ * ninth of the front-end's vector instructions.  Layout: A = 32 F2 keypoints (rows), B = 32 queries (columns), so a
+ * lane's 16 results all belong to ONE query (column lane & 31) and the per-query key list stays in its registers;
+ * a wavefront carries two query blocks (64 queries, their operands expanded once: 64 VGPRs), the workgroup's four
+ * wavefronts share the F2 operands, which are expanded from bits to bytes once per 128 keypoints into LDS in
+ * fragment order (conflict-free ds_read_b128).  The pairing of bits with operand bytes is free as long as A and B
+ * agree (the product sums over k): K-step s = descriptor word s, lane half h and byte j <-> bit 8 (j & 3) + 4 h +
+ * (j >> 2), i.e. dword i of a fragment = (W >> (4 h + i)) & 0x01010101 -- two instructions per four operand bytes.
+ * Selection: a distance matters only up to Dmax (TH_LOW, or what the ratio test can still see: k_match_knn), so
+ * a result is compared with the lane's threshold Dmax - popc(q) -- one v_cmp and one untaken scalar branch per
+ * 64 pairs -- and only a hit (a handful per query over the whole frame) runs the candidate tests and the sorted
+ * insert.  The two lanes that share a query (rows 4 h ..) merge their lists at the end.  Same keys, same lists as
+ * k_match_knn<true>: the kept set is "the MK_TOP smallest of a set of unique keys", whatever the visiting order. */
+typedef int mm_v4i __attribute__((ext_vector_type(4)));
+typedef int mm_v16i __attribute__((ext_vector_type(16)));
+#define MM_CHUNK 128 /* F2 keypoints per LDS stage: 4 row tiles of 32, 8 KB of operand bytes each */
+__device__ __forceinline__ mm_v4i mm_bits01(uint32_t W, int h) {
+    const uint32_t w = W >> (4 * h);
+    mm_v4i r;
+    r.x = (int)(w & 0x01010101u);
+    r.y = (int)((w >> 1) & 0x01010101u);
+    r.z = (int)((w >> 2) & 0x01010101u);
+    r.w = (int)((w >> 3) & 0x01010101u);
+    return r;
+}
+__device__ __forceinline__ int mm_pm1(uint32_t x) { return (int)((((x << 8) - x)) | 0x01010101u); } /* byte 1 -> 0xFF (-1), byte 0 -> +1 */
+__device__ __forceinline__ mm_v4i mm_bits_pm(uint32_t W, int h) {
+    const mm_v4i b = mm_bits01(W, h);
+    mm_v4i r;
+    r.x = mm_pm1((uint32_t)b.x);
+    r.y = mm_pm1((uint32_t)b.y);
+    r.z = mm_pm1((uint32_t)b.z);
+    r.w = mm_pm1((uint32_t)b.w);
+    return r;
+}
+/* The 16 results a lane holds of one 32 x 32 tile against the lane's threshold.  Looking at a result must cost next
+   to nothing -- there are a million per frame pair and a thousand that matter -- and must not branch: a skipped block
+   is a TAKEN branch, and 32 of those per tile cost more than the products (first version of this kernel: 181 us per
+   256 pairs against 27 us of MFMA time).  So: one subtract and one v_alignbit per result shift the sign of
+   (result - threshold - 1) into a per-lane bit mask, one wave-wide test per block and tile; the lanes with hits then
+   walk their mask bits, RECOMPUTE the distance of that (query, keypoint) pair from the raw descriptor words (query:
+   registers, keypoint: LDS; a register cannot be indexed by a lane-varying bit number) and run the candidate tests of
+   k_match_knn and the sorted insert.  One trip of that loop per tile in the common case. */
+__device__ __forceinline__ void mm_scan_tile(const mm_v16i acc, const int thr1, const uint32_t (&qw)[8], const float px, const float py,
+                                             uint32_t (&bk)[MK_TOP], const int tile, const int h, const bool brute, const float r,
+                                             const float nnratio, const uint32_t *s_o, const float *s_x, const float *s_y,
+                                             const uint4 *s_raw) {
+    const uint32_t KNONE = 0xFFFFFFFFu;
+    uint32_t mask = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) mask = __builtin_amdgcn_alignbit(mask, (uint32_t)(acc[i] - thr1), 31); /* bit 15 - i: result i <= threshold */
+    while (__builtin_amdgcn_ballot_w64(mask != 0u) != 0ull) {
+        /* straight-line for every lane (a lane without a hit looks at row 0 and drops the key): no divergent blocks */
+        const bool has = mask != 0u;
+        const int i = has ? 16 - __ffs((int)mask) : 0;
+        mask &= mask - 1u;
+        const int slot = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h; /* C/D row of register i */
+        const uint4 t0 = s_raw[2 * slot], t1 = s_raw[2 * slot + 1];
+        const uint32_t ord = s_o[slot];
+        const float dx = fabsf(s_x[slot] - px), dy = fabsf(s_y[slot] - py);
+        const int d = hamming256(qw, t0, t1);
+        const int keep = (int)has & (int)(ord != KNONE) & ((int)brute | ((int)(dx < r) & (int)(dy < r))) &
+                         ((int)(d <= TH_LOW) | (int)!((float)TH_LOW < (float)d * nnratio)); /* the tests of k_match_knn */
+        const uint32_t key = keep ? (((uint32_t)d << (brute ? 16 : 23)) | ord) : KNONE;
+#pragma unroll
+        for (int k = MK_TOP - 1; k > 0; k--) bk[k] = umed3(bk[k - 1], key, bk[k]);
+        bk[0] = key < bk[0] ? key : bk[0];
+    }
+}
+__device__ __forceinline__ void mm_merge_halves(uint32_t (&bk)[MK_TOP]) {
+    uint32_t other[MK_TOP];
+#pragma unroll
+    for (int k = 0; k < MK_TOP; k++) other[k] = (uint32_t)__shfl_xor((int)bk[k], 32);
+#pragma unroll
+    for (int j = 0; j < MK_TOP; j++) {
+        const uint32_t key = other[j];
+#pragma unroll
+        for (int k = MK_TOP - 1; k > 0; k--) bk[k] = umed3(bk[k - 1], key, bk[k]);
+        bk[0] = key < bk[0] ? key : bk[0];
+    }
+}
+template <int QB> /* query blocks of 32 per wavefront: 2 = fewer operand reads per pair, 1 = half the registers (4 waves per SIMD) */
+__global__ __launch_bounds__(256) void k_match_knn_mfma(MatchArgs A) {
+    __shared__ mm_v4i s_a[(MM_CHUNK / 32) * 8 * 64];
+    __shared__ uint4 s_raw[MM_CHUNK * 2]; /* the same keypoints' descriptors as they are: a hit recomputes its distance from these */
+    __shared__ float s_x[MM_CHUNK], s_y[MM_CHUNK];
+    __shared__ uint32_t s_o[MM_CHUNK];
+    const uint32_t KNONE = 0xFFFFFFFFu;
+    const int pair = blockIdx.y;
+    const int fa = A.pair_a ? A.pair_a[pair] : 2 * pair, fb = A.pair_b ? A.pair_b[pair] : 2 * pair + 1;
+    const int n1 = A.counts[fa], n2 = A.counts[fb];
+    if ((int)(blockIdx.x * 128 * QB) >= n1) return; /* whole block beyond the query count (uniform) */
+    const OrbKeyPoint *k1 = A.kps + (size_t)fa * A.cap, *k2 = A.kps + (size_t)fb * A.cap;
+    const uint8_t *D1 = A.desc + (size_t)fa * A.cap * 32, *D2 = A.desc + (size_t)fb * A.cap * 32;
+    const bool brute = A.window < 0;
+    const float invW = (float)GRID_COLS / (A.max_x - A.min_x), invH = (float)GRID_ROWS / (A.max_y - A.min_y);
+    const float r = (float)A.window;
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    const int qbase = blockIdx.x * 128 * QB + (threadIdx.x >> 6) * 32 * QB;
+    /* the largest distance that can matter: d <= TH_LOW, or TH_LOW >= d * ratio (the exact test is repeated on a hit) */
+    const float dq = A.nnratio > 0.0f ? (float)TH_LOW / A.nnratio : 1e9f;
+    const int Dmax = dq >= 256.0f ? 256 : max(TH_LOW, (int)dq + 1);
+    mm_v4i bq[2][8];
+    uint32_t qw0[8], qw1[8]; /* the two queries' descriptor words */
+    int thr1[2] = {0, 0};    /* threshold + 1 on the product: d <= Dmax <=> result - (Dmax - popc(q)) - 1 < 0 */
+    float px[2] = {0.0f, 0.0f}, py[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        qw1[s] = 0u;
+        bq[1][s] = mm_v4i{0, 0, 0, 0};
+    }
+    bool act_any = false;
+#pragma unroll
+    for (int b = 0; b < QB; b++) {
+        const int qi = qbase + 32 * b + c;
+        uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        bool act = false;
+        px[b] = py[b] = 0.0f;
+        if (qi < n1) {
+            const OrbKeyPoint kp1 = k1[qi];
+            act = brute || kp1.octave == 0; /* :26-28 */
+            px[b] = kp1.x;
+            py[b] = kp1.y;
+            if (A.prev_xy) {
+                px[b] = A.prev_xy[((size_t)pair * A.cap + qi) * 2];
+                py[b] = A.prev_xy[((size_t)pair * A.cap + qi) * 2 + 1];
+            }
+            const uint4 *p = (const uint4 *)(D1 + (size_t)qi * 32);
+            const uint4 v0 = p[0], v1 = p[1];
+            w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w;
+            w[4] = v1.x; w[5] = v1.y; w[6] = v1.z; w[7] = v1.w;
+        }
+        int pc = 0;
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            pc += __popc(w[s]);
+            bq[b][s] = mm_bits_pm(w[s], h);
+            if (b == 0) qw0[s] = w[s]; else qw1[s] = w[s];
+        }
+        thr1[b] = act ? Dmax - pc + 1 : -100000; /* a result is >= -256: an inactive query never hits */
+        act_any = act_any || act;
+    }
+    uint32_t bk0[MK_TOP], bk1[MK_TOP]; /* per query block: the MK_TOP smallest keys this lane has seen, ascending */
+#pragma unroll
+    for (int k = 0; k < MK_TOP; k++) bk0[k] = bk1[k] = KNONE;
+    const bool any_active = __syncthreads_or(act_any) != 0;
+    /* staging roles: thread t < 128 owns the candidate record of F2 keypoint t of the chunk; every thread fetches one half
+       descriptor (16 B, coalesced) and expands its four words.  The next chunk's global loads are issued before the
+       current one is consumed. */
+    const int ej = threadIdx.x >> 1, eh = threadIdx.x & 1; /* keypoint ej of the chunk, words 4 eh .. 4 eh + 3 */
+    uint4 Wn = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t on = KNONE;
+    float xn = 0.0f, yn = 0.0f;
+#define MM_FETCH(T0)                                                                                                   \
+    {                                                                                                                  \
+        Wn = (T0) + ej < n2 ? ((const uint4 *)(D2 + (size_t)((T0) + ej) * 32))[eh] : make_uint4(0u, 0u, 0u, 0u);        \
+        on = KNONE;                                                                                                    \
+        if (threadIdx.x < MM_CHUNK && (T0) + (int)threadIdx.x < n2) {                                                  \
+            const OrbKeyPoint kp_ = k2[(T0) + threadIdx.x];                                                            \
+            const uint32_t ord_ = f2_order_key(kp_, (T0) + threadIdx.x, brute, A.min_x, A.min_y, invW, invH);          \
+            if (ord_ != 0xFFFFFFFFu) on = brute ? ord_ : ((ord_ >> 16) << 11 | (ord_ & 0x7FFu)); /* cell << 11 | index */ \
+            xn = kp_.x;                                                                                                \
+            yn = kp_.y;                                                                                                \
+        }                                                                                                              \
+    }
+    if (any_active && n2 > 0) MM_FETCH(0)
+    for (int t0 = 0; any_active && t0 < n2; t0 += MM_CHUNK) {
+        const int nt = min(MM_CHUNK, n2 - t0);
+        __syncthreads(); /* the previous chunk has been consumed */
+        if (threadIdx.x < MM_CHUNK) {
+            s_o[threadIdx.x] = on;
+            s_x[threadIdx.x] = xn;
+            s_y[threadIdx.x] = yn;
+        }
+        {
+            const int base = ((ej >> 5) * 8 + 4 * eh) * 64 + (ej & 31); /* tile ej / 32, K-step 4 eh + k, row ej % 32 */
+            s_raw[threadIdx.x] = Wn;
+            s_a[base] = mm_bits01(Wn.x, 0);
+            s_a[base + 32] = mm_bits01(Wn.x, 1);
+            s_a[base + 64] = mm_bits01(Wn.y, 0);
+            s_a[base + 96] = mm_bits01(Wn.y, 1);
+            s_a[base + 128] = mm_bits01(Wn.z, 0);
+            s_a[base + 160] = mm_bits01(Wn.z, 1);
+            s_a[base + 192] = mm_bits01(Wn.w, 0);
+            s_a[base + 224] = mm_bits01(Wn.w, 1);
+        }
+        __syncthreads();
+        if (t0 + MM_CHUNK < n2) MM_FETCH(t0 + MM_CHUNK)
+        const int ntile = (nt + 31) >> 5;
+        for (int tile = 0; tile < ntile; tile++) {
+            mm_v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                const mm_v4i a = s_a[(tile * 8 + s) * 64 + lane];
+                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[0][s], acc0, 0, 0, 0);
+                if (QB == 2) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[1][s], acc1, 0, 0, 0);
+            }
+            mm_scan_tile(acc0, thr1[0], qw0, px[0], py[0], bk0, tile, h, brute, r, A.nnratio, s_o, s_x, s_y, s_raw);
+            if (QB == 2) mm_scan_tile(acc1, thr1[1], qw1, px[1], py[1], bk1, tile, h, brute, r, A.nnratio, s_o, s_x, s_y, s_raw);
+        }
+    }
+    /* lanes c and c + 32 hold the two halves (rows 4 h ..) of the same queries: each takes in the other's keys */
+    mm_merge_halves(bk0);
+    if (QB == 2) mm_merge_halves(bk1);
+    /* QB = 2: lane (c, h) writes query 32 h + c of the wavefront = block h, column c; QB = 1: the lower half writes */
+    const int i1 = QB == 2 ? qbase + lane : qbase + c;
+    if (i1 < n1 && (QB == 2 || h == 0)) {
+        uint64_t out[MK_TOP];
+#pragma unroll
+        for (int k = 0; k < MK_TOP; k++) {
+            const uint32_t k32 = (QB == 2 && h) ? bk1[k] : bk0[k];
+            if (k32 == KNONE)
+                out[k] = ~0ull;
+            else if (brute)
+                out[k] = ((uint64_t)(k32 >> 16) << 32) | (k32 & 0xFFFFu);
+            else
+                out[k] = ((uint64_t)(k32 >> 23) << 32) | (uint64_t)((((k32 >> 11) & 0xFFFu) << 16) | (k32 & 0x7FFu));
+        }
+#pragma unroll
+        for (int k = 0; k < MK_TOP / 2; k++)
+            A.knn[((size_t)pair * A.cap + i1) * (MK_TOP / 2) + k] = make_ulonglong2(out[2 * k], out[2 * k + 1]);
+    }
+}
+
 /* PHASE 2 (serial resolution) -- one wavefront per frame pair; dynamic LDS: per F2 keypoint {float x,y; u32 ord; i32 m21; float angle; u16 mdist} */
 __global__ __launch_bounds__(64) void k_match_init(MatchArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -981,7 +1209,13 @@ static int launch_match(const MatchArgs &A_in, int n_pairs, hipStream_t st, hipE
     }
     static PerDeviceLdsLimit lim;
     MCHK(lim.ensure((const void *)k_match_init, lds));
-    if (A.cap <= (A.window < 0 ? 65536 : 2048))
+    static const int no_mfma = getenv("ORBSLAM_AMD_MATCH_NO_MFMA") ? 1 : 0; /* diagnostics: the xor / popcount scan */
+    static const int mfma_qb = getenv("ORBSLAM_AMD_MATCH_QB") ? atoi(getenv("ORBSLAM_AMD_MATCH_QB")) : 1;
+    if (A.cap <= (A.window < 0 ? 65536 : 2048) && !no_mfma && mfma_qb == 1)
+        hipLaunchKernelGGL(k_match_knn_mfma<1>, dim3((A.cap + 127) / 128, n_pairs), dim3(256), 0, st, A);
+    else if (A.cap <= (A.window < 0 ? 65536 : 2048) && !no_mfma)
+        hipLaunchKernelGGL(k_match_knn_mfma<2>, dim3((A.cap + 255) / 256, n_pairs), dim3(256), 0, st, A);
+    else if (A.cap <= (A.window < 0 ? 65536 : 2048))
         hipLaunchKernelGGL(k_match_knn<true>, dim3((A.cap + 255) / 256, n_pairs), dim3(256), 0, st, A);
     else
         hipLaunchKernelGGL(k_match_knn<false>, dim3((A.cap + 255) / 256, n_pairs), dim3(256), 0, st, A);

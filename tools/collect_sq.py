@@ -30,6 +30,8 @@ def main():
         for f in glob.glob(d + "/*counter_collection.csv") + glob.glob(d + "/*/*counter_collection.csv"):
             for r in csv.DictReader(open(f)):
                 name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+                if name == "k_match_knn_mfma":  # phase 1 of the matcher on the matrix cores: same stage as k_match_knn
+                    name = "k_match_knn"
                 if name not in KERNELS:
                     continue
                 c = r["Counter_Name"]

@@ -41,6 +41,8 @@ def load(d, counter):
         if r["Counter_Name"] != counter:
             continue
         name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+        if name == "k_match_knn_mfma":  # phase 1 of the matcher on the matrix cores: same stage as k_match_knn
+            name = "k_match_knn"
         if name == "k_ba_iteration" and int(r["Grid_Size"]) != BA_BATCH * 512:
             continue
         if name.startswith("k_ba_ph_"):  # the batch path as phase kernels: everything between two k_ba_ph_round launches is one round
