@@ -77,111 +77,174 @@ __device__ __forceinline__ void sincos_det(float angle, float *c_out, float *s_o
     *s_out = (float)sv;
 }
 
+/* One workgroup = 4 wavefronts x SPW keypoint slots, in three phases that share LDS:
+ *   1. (wavefront per slot) intensity-centroid moments.  The 31 x 31 patch is read as 31 rows x 8 (unaligned)
+ *      dwords, four per lane, and the circular mask and the column weights ride in two byte-weight dwords per
+ *      (row, dword): row sum S0 = dot4(I, mask), S1 = dot4(I, (u + 15) * mask); m01 = sum v * S0,
+ *      m10 = sum S1 - 15 * sum S0.  Two v_dot4_u32_u8 per dword where a column-per-lane walk spent ~10
+ *      instructions per row on HALF the lanes.
+ *   2. (one LANE per slot) cv::fastAtan2 and the deterministic double-precision sin / cos.  They are ~90 vector
+ *      instructions -- two dozen in f64 -- which a wavefront-per-keypoint kernel issues once PER KEYPOINT for 64
+ *      identical lanes; here the 4 x SPW slots of the workgroup share one issue of them.
+ *   3. (wavefront per slot) steered BRIEF: lane L evaluates bits L, L + 64, L + 128, L + 192; a ballot of each group
+ *      is 8 descriptor bytes.
+ * SPW = 16 for batches (the trig phase costs a sixty-fourth per keypoint), SPW = 1 for calls of a few frames, where
+ * a frame's thousand keypoints must spread over the whole device rather than queue sixteen deep in 17 workgroups.
+ * Integer moments are exact in any order and the float / double steps are the same functions on the same inputs:
+ * bit-identical to the previous kernel and to the oracle. */
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+template <int SPW>
 __global__ __launch_bounds__(256) void k_describe(OrbGeom g, const uint8_t *pyr, const uint8_t *blur,
                                                    const uint32_t *lvl_kp, const int32_t *lvl_cnt, OrbKeyPoint *kps,
                                                    uint8_t *desc, int cap, int32_t *counts) {
+    constexpr int SLOTS = 4 * SPW;
+    __shared__ uint32_t s_w[248 * 2]; /* per (row, dword) of the patch: mask bytes, (u + 15) * mask bytes */
+    __shared__ int s_lvl[SLOTS], s_oi[SLOTS], s_m01[SLOTS], s_m10[SLOTS];
+    __shared__ uint32_t s_key[SLOTS];
+    __shared__ float s_ang[SLOTS], s_a[SLOTS], s_b[SLOTS];
     /* all keypoints of one frame run on ONE XCD (consecutive remapped items share an L2): the frame's pyramid and
        blurred pyramid (2 MB) then stay L2-resident while its ~1000 patches are gathered from them */
     const int item = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const int frame = item / (int)gridDim.x, bx = item - frame * (int)gridDim.x;
-    const int lane = threadIdx.x & 63;
-    /* wave-uniform by construction; readfirstlane tells the compiler, which then keeps the level search, the geometry
-       reads and every derived pointer on the scalar unit */
-    const int slot = bx * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); /* slot in the frame's level-kp array */
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int32_t *lc = lvl_cnt + (int64_t)frame * g.nlevels;
-    int level = 0, before = 0;
-    while (level + 1 < g.nlevels && slot >= g.lv[level + 1].out_base) {
-        before += lc[level];
-        level++;
+    if (tid < 248) {
+        const int row = tid >> 3, dw = tid & 7, v = row - 15, um = c_umax[v < 0 ? -v : v];
+        uint32_t mw = 0, uw = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int u = dw * 4 + k - 15;
+            if (u >= -um && u <= um) {
+                mw |= 1u << (8 * k);
+                uw |= (uint32_t)(u + 15) << (8 * k);
+            }
+        }
+        s_w[2 * tid] = mw;
+        s_w[2 * tid + 1] = uw;
     }
-    if (slot == 0 && lane == 0) {
+    if (tid < SLOTS) { /* slot -> (level, position in the concatenated output (:1035-1063)) */
+        const int slot = bx * SLOTS + tid;
+        int level = 0, before = 0, cnt = lc[0], prefix = 0;
+        for (int l = 1; l < g.nlevels; l++) {
+            prefix += lc[l - 1];
+            if (slot >= g.lv[l].out_base) {
+                level = l;
+                before = prefix;
+                cnt = lc[l];
+            }
+        }
+        int base = 0;
+        for (int l = 1; l < g.nlevels; l++) base = slot >= g.lv[l].out_base ? g.lv[l].out_base : base;
+        const int idx = slot - base, oi = before + idx;
+        const bool valid = slot < g.total_out_cap && idx < cnt && oi < cap;
+        s_lvl[tid] = valid ? level : -1;
+        s_oi[tid] = oi;
+        s_key[tid] = valid ? lvl_kp[(int64_t)frame * g.total_out_cap + slot] : 0u;
+    }
+    if (bx == 0 && tid == 0) {
         int tot = 0;
         for (int l = 0; l < g.nlevels; l++) tot += lc[l];
         counts[frame] = tot < cap ? tot : cap;
     }
-    if (slot >= g.total_out_cap) return;
-    const LevelGeom &L = g.lv[level];
-    const int idx = slot - L.out_base;
-    if (idx >= lc[level]) return;
-    const int oi = before + idx; /* position in the concatenated output (:1035-1063) */
-    if (oi >= cap) return;
-    /* the keypoint is the same for the whole wavefront: keep it (and every pointer derived from it) in SGPRs, so
-       that each patch / pattern read is "uniform base + 32-bit lane offset" instead of 64-bit pointer arithmetic
-       per lane and load */
-    const uint32_t key = (uint32_t)__builtin_amdgcn_readfirstlane((int)lvl_kp[(int64_t)frame * g.total_out_cap + slot]);
-    const int px = KEY_X(key) + ORB_MIN_BORDER, py = KEY_Y(key) + ORB_MIN_BORDER; /* :799-800 */
-    const int pitch = L.pitch;
-
-    /* ---- IC_Angle on the un-blurred level ---- */
-    const uint8_t *img = level_ptr(pyr, g, frame, level);
-    const uint8_t *patch = img + (int64_t)(py - 15) * pitch + (px - 15); /* top-left of the 31 x 31 patch: offsets >= 0 */
-    int m10 = 0, m01 = 0;
-    {
-        const int u = lane - 15;
-        if (lane < 31) {
-            const uint32_t col = (uint32_t)lane; /* = u + 15 */
-            /* all 31 rows of this lane's column are fetched unconditionally (the 31 x 31 square lies inside the
-               image: EDGE_THRESHOLD 19 > 15) and BEFORE any of them is used -- one memory round trip instead of
-               fifteen dependent ones behind the circular-mask branches; the mask is applied to the arithmetic */
-            int vp[16], vm[16];
-            const int ctr = patch[col + 15u * (uint32_t)pitch];
+    __syncthreads();
+    /* ---- 1. IC_Angle moments on the un-blurred level ---- */
+    for (int k = 0; k < SPW; k++) {
+        const int sl = wave * SPW + k;
+        const int level = __builtin_amdgcn_readfirstlane(s_lvl[sl]);
+        if (level < 0) continue;
+        /* the keypoint is the same for the whole wavefront: it (and every pointer derived from it) stays in SGPRs */
+        const uint32_t key = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_key[sl]);
+        const LevelGeom &L = g.lv[level];
+        const int px = KEY_X(key) + ORB_MIN_BORDER, py = KEY_Y(key) + ORB_MIN_BORDER; /* :799-800 */
+        const int pitch = L.pitch;
+        const uint8_t *patch = level_ptr(pyr, g, frame, level) + (int64_t)(py - 15) * pitch + (px - 15); /* top-left of the 31 x 31 patch */
+        uint32_t I[4];
 #pragma unroll
-            for (int v = 1; v <= 15; v++) {
-                vp[v] = patch[col + (uint32_t)(15 + v) * (uint32_t)pitch];
-                vm[v] = patch[col + (uint32_t)(15 - v) * (uint32_t)pitch];
-            }
-            m10 = u * ctr;
+        for (int j = 0; j < 4; j++) { /* the 31 x 32-byte window lies inside the image: EDGE_THRESHOLD 19 > 16 */
+            const int i = min(lane + 64 * j, 247);
+            I[j] = *(const u32_unaligned *)(patch + (uint32_t)(__mul24(i >> 3, pitch) + (i & 7) * 4));
+        }
+        int m01 = 0;
+        uint32_t s0 = 0, s1 = 0;
 #pragma unroll
-            for (int v = 1; v <= 15; v++) {
-                const bool in = u >= -c_umax[v] && u <= c_umax[v];
-                m01 += in ? v * (vp[v] - vm[v]) : 0;
-                m10 += in ? u * (vp[v] + vm[v]) : 0;
+        for (int j = 0; j < 4; j++) {
+            const int i = lane + 64 * j;
+            if (i < 248) {
+                const uint32_t r0 = __builtin_amdgcn_udot4(I[j], s_w[2 * i], 0u, false);
+                s1 = __builtin_amdgcn_udot4(I[j], s_w[2 * i + 1], s1, false);
+                s0 += r0;
+                m01 += ((i >> 3) - 15) * (int)r0;
             }
         }
+        int m10 = (int)s1 - 15 * (int)s0;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             m10 += __shfl_xor(m10, o);
             m01 += __shfl_xor(m01, o);
         }
-    }
-    const float angle = fast_atan2_deg((float)m01, (float)m10);
-
-    /* ---- steered BRIEF on the blurred level ---- */
-    const float factorPI = (float)(3.14159265358979323846 / 180.f);
-    float a, b;
-    sincos_det(angle * factorPI, &a, &b);
-    /* rotated pattern points stay within +-19 px of the keypoint (|p| <= 13 per axis, EDGE_THRESHOLD 19) */
-    const uint8_t *bc = level_ptr(blur, g, frame, level) + (int64_t)(py - 20) * pitch + (px - 20);
-    uint64_t words[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int bit = j * 64 + lane;
-        const int8_t *p = c_pattern + bit * 4;
-        const float x0 = (float)p[0], y0 = (float)p[1], x1 = (float)p[2], y1 = (float)p[3];
-        const int r0 = (int)rintf(x0 * b + y0 * a), q0 = (int)rintf(x0 * a - y0 * b);
-        const int r1 = (int)rintf(x1 * b + y1 * a), q1 = (int)rintf(x1 * a - y1 * b);
-        const int t0 = bc[(uint32_t)(__mul24(r0 + 20, pitch) + q0 + 20)], t1 = bc[(uint32_t)(__mul24(r1 + 20, pitch) + q1 + 20)];
-        words[j] = __ballot(t0 < t1);
-    }
-    if (lane < 4) {
-        uint64_t w = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
-        *(uint64_t *)(desc + ((int64_t)frame * cap + oi) * 32 + lane * 8) = w;
-    }
-    if (lane == 0) {
-        OrbKeyPoint kp;
-        float fx = (float)px, fy = (float)py;
-        if (level != 0) { /* :1055-1061 */
-            fx *= L.scale;
-            fy *= L.scale;
+        if (lane == 0) {
+            s_m01[sl] = m01;
+            s_m10[sl] = m10;
         }
-        kp.x = fx;
-        kp.y = fy;
-        kp.size = L.patch_size;
-        kp.angle = angle;
-        kp.response = (float)KEY_R(key);
-        kp.octave = level;
-        kp.class_id = -1;
-        kps[(int64_t)frame * cap + oi] = kp;
+    }
+    __syncthreads();
+    /* ---- 2. angle and rotation, one lane per slot ---- */
+    if (tid < SLOTS && s_lvl[tid] >= 0) {
+        const float angle = fast_atan2_deg((float)s_m01[tid], (float)s_m10[tid]);
+        const float factorPI = (float)(3.14159265358979323846 / 180.f);
+        float a, b;
+        sincos_det(angle * factorPI, &a, &b);
+        s_ang[tid] = angle;
+        s_a[tid] = a;
+        s_b[tid] = b;
+    }
+    __syncthreads();
+    /* ---- 3. steered BRIEF on the blurred level ---- */
+    for (int k = 0; k < SPW; k++) {
+        const int sl = wave * SPW + k;
+        const int level = __builtin_amdgcn_readfirstlane(s_lvl[sl]);
+        if (level < 0) continue;
+        const uint32_t key = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_key[sl]);
+        const int oi = __builtin_amdgcn_readfirstlane(s_oi[sl]);
+        const float a = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_a[sl])));
+        const float b = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_b[sl])));
+        const LevelGeom &L = g.lv[level];
+        const int px = KEY_X(key) + ORB_MIN_BORDER, py = KEY_Y(key) + ORB_MIN_BORDER;
+        const int pitch = L.pitch;
+        /* rotated pattern points stay within +-19 px of the keypoint (|p| <= 13 per axis, EDGE_THRESHOLD 19) */
+        const uint8_t *bc = level_ptr(blur, g, frame, level) + (int64_t)(py - 20) * pitch + (px - 20);
+        uint64_t words[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int bit = j * 64 + lane;
+            const int8_t *p = c_pattern + bit * 4;
+            const float x0 = (float)p[0], y0 = (float)p[1], x1 = (float)p[2], y1 = (float)p[3];
+            const int r0 = (int)rintf(x0 * b + y0 * a), q0 = (int)rintf(x0 * a - y0 * b);
+            const int r1 = (int)rintf(x1 * b + y1 * a), q1 = (int)rintf(x1 * a - y1 * b);
+            const int t0 = bc[(uint32_t)(__mul24(r0 + 20, pitch) + q0 + 20)], t1 = bc[(uint32_t)(__mul24(r1 + 20, pitch) + q1 + 20)];
+            words[j] = __ballot(t0 < t1);
+        }
+        if (lane < 4) {
+            uint64_t w = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
+            *(uint64_t *)(desc + ((int64_t)frame * cap + oi) * 32 + lane * 8) = w;
+        }
+        if (lane == 0) {
+            OrbKeyPoint kp;
+            float fx = (float)px, fy = (float)py;
+            if (level != 0) { /* :1055-1061 */
+                fx *= L.scale;
+                fy *= L.scale;
+            }
+            kp.x = fx;
+            kp.y = fy;
+            kp.size = L.patch_size;
+            kp.angle = s_ang[sl];
+            kp.response = (float)KEY_R(key);
+            kp.octave = level;
+            kp.class_id = -1;
+            kps[(int64_t)frame * cap + oi] = kp;
+        }
     }
 }
 
@@ -201,8 +264,15 @@ hipError_t orb_upload_constants(int device, hipStream_t stream) {
 
 hipError_t launch_describe(const OrbGeom &g, const OrbBuffers &b, int n_frames, OrbKeyPoint *d_kps, uint8_t *d_desc,
                            int cap, int32_t *d_counts, hipStream_t st) {
-    dim3 grid((g.total_out_cap + 3) / 4, n_frames);
-    hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, st, g, (const uint8_t *)b.pyr, (const uint8_t *)b.blur,
-                       (const uint32_t *)b.lvl_kp, (const int32_t *)b.lvl_cnt, d_kps, d_desc, cap, d_counts);
+    static const int wide_min = getenv("ORBSLAM_AMD_DESC_BATCH_MIN") ? atoi(getenv("ORBSLAM_AMD_DESC_BATCH_MIN")) : 16;
+    if (n_frames >= wide_min) { /* 64 slots per workgroup: the trig phase is shared by 64 keypoints */
+        dim3 grid((g.total_out_cap + 63) / 64, n_frames);
+        hipLaunchKernelGGL(k_describe<16>, grid, dim3(256), 0, st, g, (const uint8_t *)b.pyr, (const uint8_t *)b.blur,
+                           (const uint32_t *)b.lvl_kp, (const int32_t *)b.lvl_cnt, d_kps, d_desc, cap, d_counts);
+    } else {
+        dim3 grid((g.total_out_cap + 3) / 4, n_frames);
+        hipLaunchKernelGGL(k_describe<1>, grid, dim3(256), 0, st, g, (const uint8_t *)b.pyr, (const uint8_t *)b.blur,
+                           (const uint32_t *)b.lvl_kp, (const int32_t *)b.lvl_cnt, d_kps, d_desc, cap, d_counts);
+    }
     return hipGetLastError();
 }
