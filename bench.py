@@ -214,11 +214,11 @@ def single_stream(n_frames):
         env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF"))}
         rec_dt = np.dtype([("pose", "<f8", 7), ("nm", "<i4"), ("inl", "<i4")])
 
-        def run(binary, out):
+        def run(binary, out, *extra):
             best = None
             for _ in range(4):   # the first run pages the binary and the library in, and an idle GPU takes a few hundred ms to clock up
                 p = subprocess.run([binary, str(frames.shape[2]), str(frames.shape[1]), str(n_frames), td + "/f.raw", td + "/gt.bin",
-                                    *("%.17g" % v for v in K), out], capture_output=True, text=True, timeout=300, env=env)
+                                    *("%.17g" % v for v in K), out, *extra], capture_output=True, text=True, timeout=300, env=env)
                 if p.returncode != 0:
                     raise RuntimeError("%s exited with %d: %s" % (os.path.basename(binary), p.returncode, p.stderr[-200:]))
                 j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
@@ -247,6 +247,15 @@ def single_stream(n_frames):
                                "ate_rmse_m": round(sq.ate_rmse(rec2["pose"].copy(), gt), 5),
                                "mean_matches": round(float(rec2["nm"][1:].mean()), 1),
                                "mean_inliers": round(float(rec2["inl"][1:].mean()), 1)}
+        # ... and with the look-ahead of a recorded sequence: frame k + 1 is uploaded and extracted on a second stream beside
+        # the search and the pose problem of frame k (orb_tracker_track_prefetch); same matches, same poses
+        j3, rec3 = run(exe2, td + "/out3.bin", "prefetch")
+        res["device_chain"]["with_lookahead"] = {
+            "value": round((n_frames - 1) / j3["track_secs"], 1), "unit": "frames/s",
+            "ms_per_frame": round(j3["track_secs"] / (n_frames - 1) * 1e3, 4),
+            "what": "orb_tracker_track_prefetch: the next frame's upload + extraction overlap this frame's search and pose problem",
+            "same_results": bool(np.array_equal(rec3["nm"], rec2["nm"]) and np.array_equal(rec3["inl"], rec2["inl"])
+                                 and np.array_equal(rec3["pose"], rec2["pose"]))}
         return res
     except Exception as e:   # a missing host compiler must not cost the driver its line
         return {"error": "%s: %s" % (type(e).__name__, e)}

@@ -328,6 +328,16 @@ int orb_tracker_track(OrbTracker *t, const uint8_t *gray, int w, int h, int stri
                       float min_y, float max_y, float th, int check_orientation, OrbKeyPoint *kps_out, uint8_t *desc_out, int cap,
                       int32_t *n_out, int32_t *cur_match, uint8_t *outlier, double *pose_out7, int32_t *n_matches,
                       int32_t *n_inliers);
+/* The same call with a LOOK-AHEAD for callers that hold the next frame already (a recorded sequence, a camera queue):
+ * next_gray (same w / h / stride; NULL = none) is uploaded and run through the extractor on a second stream WHILE this
+ * frame's search and pose problem run, and the call that then passes that very buffer as `gray` finds its features in
+ * device memory (a call with any other buffer drops the look-ahead).  Extraction does not depend on the pose, so the
+ * results are those of orb_tracker_track bit for bit; the buffer behind next_gray must stay unchanged until that call. */
+int orb_tracker_track_prefetch(OrbTracker *t, const uint8_t *gray, int w, int h, int stride, const uint8_t *prev_flags,
+                               const double *prev_xw, int n_prev, const double *pose_pred7, double fx, double fy, double cx, double cy,
+                               float min_x, float max_x, float min_y, float max_y, float th, int check_orientation,
+                               OrbKeyPoint *kps_out, uint8_t *desc_out, int cap, int32_t *n_out, int32_t *cur_match, uint8_t *outlier,
+                               double *pose_out7, int32_t *n_matches, int32_t *n_inliers, const uint8_t *next_gray);
 
 #ifdef __cplusplus
 }

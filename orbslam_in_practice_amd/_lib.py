@@ -61,7 +61,7 @@ EXPORTS = [
     "orb_set_profiling", "orb_get_stage_ms", "orb_matcher_set_profiling", "orb_matcher_get_ms", "orb_matcher_get_stage_ms", "orb_features_in_area",
     "orb_descriptor_distance", "orb_compute_three_maxima", "orb_matcher_create", "orb_matcher_destroy",
     "orb_matcher_stream", "orb_matcher_synchronize", "orb_hamming_knn2", "orb_match_init",
-    "orb_match_batch_device", "orb_search_by_projection", "orb_search_by_projection_device", "orb_search_by_bow", "orb_tracker_create", "orb_tracker_destroy", "orb_tracker_reset", "orb_tracker_track", "ba_pose_optimization_matches_device", "ba_create", "ba_destroy", "ba_solve", "ba_solve_batch", "ba_submit_batch", "ba_wait", "ba_set_profiling", "ba_get_iteration_ms",
+    "orb_match_batch_device", "orb_search_by_projection", "orb_search_by_projection_device", "orb_search_by_bow", "orb_tracker_create", "orb_tracker_destroy", "orb_tracker_reset", "orb_tracker_track_prefetch", "orb_tracker_track", "ba_pose_optimization_matches_device", "ba_create", "ba_destroy", "ba_solve", "ba_solve_batch", "ba_submit_batch", "ba_wait", "ba_set_profiling", "ba_get_iteration_ms",
     "ba_pose_optimization", "ba_pose_optimization_batch",
 ]
 
@@ -168,6 +168,7 @@ def lib():
     L.orb_tracker_reset.argtypes = [vp]
     L.orb_tracker_track.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, vp, C.c_double, C.c_double, C.c_double, C.c_double, f32, f32, f32,
                                     f32, f32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
+    L.orb_tracker_track_prefetch.argtypes = L.orb_tracker_track.argtypes + [vp]
     L.ba_pose_optimization_matches_device.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, i32, C.c_double, C.c_double, C.c_double,
                                                       C.c_double, vp, vp, vp, vp]
     L.ba_create.argtypes = [i32, i32, i32, i32, i32, C.POINTER(vp)]

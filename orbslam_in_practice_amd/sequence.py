@@ -141,8 +141,11 @@ class TrackerBackend(GpuBackend):
         super().__init__(nfeatures, w, h, device)
         self.tracker = self.oa.Tracker(self.ext, self.matcher, self.opt, device)
 
-    def track(self, img, last_flags, last_xw, pose_pred, K, th):
-        return self.tracker.track(img, last_flags, last_xw, pose_pred, K[0], K[1], K[2], K[3], self.bounds, th, True)
+    def track(self, img, last_flags, last_xw, pose_pred, K, th, next_gray=None):
+        return self.tracker.track(img, last_flags, last_xw, pose_pred, K[0], K[1], K[2], K[3], self.bounds, th, True, next_gray=next_gray)
+
+    def reset(self):
+        self.tracker.reset()
 
     def close(self):
         self.tracker.close()
@@ -174,7 +177,9 @@ def run_sequence(backend, frames, K, pose0, kf_every=4, ba_window=5, th=15.0):
     fused = hasattr(backend, "track")   # a backend that runs a frame's three calls as one device chain
     # frame 0: pose given, every keypoint becomes a map point
     if fused:
-        r0 = backend.track(frames[0], np.zeros(0, np.uint8), np.zeros((0, 3)), np.asarray(pose0, np.float64), K, th)
+        # (a recorded sequence: frame k + 1 is handed over with frame k and extracted beside its search and pose problem)
+        ahead = lambda k: frames[k + 1] if (k + 1 < len(frames) and frames[k + 1].flags["C_CONTIGUOUS"] and frames[k + 1].dtype == np.uint8) else None
+        r0 = backend.track(frames[0], np.zeros(0, np.uint8), np.zeros((0, 3)), np.asarray(pose0, np.float64), K, th, next_gray=ahead(0))
         kps, desc = r0["kps"], r0["desc"]
     else:
         kps, desc = backend.extract(frames[0])
@@ -200,7 +205,7 @@ def run_sequence(backend, frames, K, pose0, kf_every=4, ba_window=5, th=15.0):
         pose_pred = np.concatenate([R_to_quat(Rp), tp])
         res = None
         if fused:
-            res = backend.track(frames[k], flags, xw, pose_pred, K, th)
+            res = backend.track(frames[k], flags, xw, pose_pred, K, th, next_gray=ahead(k))
             kps, desc, nm, m = res["kps"], res["desc"], res["n_matches"], res["match"]
         else:
             kps, desc = backend.extract(frames[k])

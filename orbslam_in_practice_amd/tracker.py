@@ -32,9 +32,10 @@ class Tracker:
     def reset(self):
         check(self._L.orb_tracker_reset(self._t))
 
-    def track(self, gray, prev_flags, prev_xw, pose_pred, fx, fy, cx, cy, bounds, th, check_ori=True):
+    def track(self, gray, prev_flags, prev_xw, pose_pred, fx, fy, cx, cy, bounds, th, check_ori=True, next_gray=None):
         """returns dict(kps, desc, match[n], outlier[n], pose[7], n_matches, n_inliers); prev_flags / prev_xw empty on the
-        first frame"""
+        first frame.  next_gray: the frame the NEXT call will pass (the very same contiguous uint8 array), uploaded and
+        extracted beside this frame's search and pose problem (orb_tracker_track_prefetch)"""
         img = np.ascontiguousarray(gray, np.uint8)
         h, w = img.shape
         fl = np.ascontiguousarray(prev_flags, np.uint8)
@@ -49,10 +50,15 @@ class Tracker:
         outl = np.zeros(cap, np.uint8)
         pose_out = np.zeros(7)
         n, nm, ninl = C.c_int32(0), C.c_int32(0), C.c_int32(0)
-        check(self._L.orb_tracker_track(self._t, ptr(img), w, h, img.strides[0], ptr(fl) if n_prev else None, ptr(xw) if n_prev else None,
-                                        n_prev, ptr(pose), fx, fy, cx, cy, bounds[0], bounds[1], bounds[2], bounds[3], float(th),
-                                        int(check_ori), ptr(kps), ptr(desc), cap, C.byref(n), ptr(match), ptr(outl), ptr(pose_out),
-                                        C.byref(nm), C.byref(ninl)))
+        nxt = None
+        if next_gray is not None:  # look-ahead: the caller keeps this array alive and unchanged until it passes it as `gray`
+            nxt = next_gray
+            assert nxt.dtype == np.uint8 and nxt.flags["C_CONTIGUOUS"] and nxt.shape == img.shape
+        check(self._L.orb_tracker_track_prefetch(self._t, ptr(img), w, h, img.strides[0], ptr(fl) if n_prev else None,
+                                                 ptr(xw) if n_prev else None, n_prev, ptr(pose), fx, fy, cx, cy, bounds[0], bounds[1],
+                                                 bounds[2], bounds[3], float(th), int(check_ori), ptr(kps), ptr(desc), cap, C.byref(n),
+                                                 ptr(match), ptr(outl), ptr(pose_out), C.byref(nm), C.byref(ninl),
+                                                 ptr(nxt) if nxt is not None else None))
         k = n.value
         return dict(kps=kps[:k].copy(), desc=desc[:k].copy(), match=match[:k].copy(), outlier=outl[:k].copy(), pose=pose_out,
                     n_matches=nm.value, n_inliers=ninl.value)

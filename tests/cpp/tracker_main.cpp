@@ -92,6 +92,7 @@ int main(int argc, char **argv) {
     if (orb_tracker_create(ext, mat, sol, 0, &trk) != ORB_OK) return 4;
     const int kf_every = 4;
     const float th = 15.f;
+    const bool prefetch = argc > 11 && std::strcmp(argv[11], "prefetch") == 0;
     std::vector<int32_t> match(cap), out_nm(n, 0), out_inl(n, 0);
     std::vector<uint8_t> outl(cap), flags, flags_cur;
     std::vector<double> xw, xw_cur, out_pose((size_t)n * 7);
@@ -119,9 +120,11 @@ int main(int argc, char **argv) {
         int32_t nk = 0, nm = 0, ninl = 0;
         double pose[7];
         const auto tq = std::chrono::steady_clock::now();
-        const int rc = orb_tracker_track(trk, raw.data() + (size_t)k * w * h, w, h, w, k ? flags.data() : nullptr, k ? xw.data() : nullptr,
-                                         k ? n_last : 0, pred, fx, fy, cx, cy, 0.f, (float)w, 0.f, (float)h, th, 1, kps.data(), desc.data(), cap,
-                                         &nk, match.data(), outl.data(), pose, &nm, &ninl);
+        /* look-ahead (argv[11] = "prefetch"): the whole sequence is in memory, so frame k + 1 is handed over with frame k */
+        const unsigned char *next = (prefetch && k + 1 < n) ? raw.data() + (size_t)(k + 1) * w * h : nullptr;
+        const int rc = orb_tracker_track_prefetch(trk, raw.data() + (size_t)k * w * h, w, h, w, k ? flags.data() : nullptr,
+                                                  k ? xw.data() : nullptr, k ? n_last : 0, pred, fx, fy, cx, cy, 0.f, (float)w, 0.f, (float)h, th,
+                                                  1, kps.data(), desc.data(), cap, &nk, match.data(), outl.data(), pose, &nm, &ninl, next);
         if (k) t_track += std::chrono::duration<double>(std::chrono::steady_clock::now() - tq).count();
         if (rc != ORB_OK) {
             std::fprintf(stderr, "orb_tracker_track: %d %s\n", rc, orb_last_error());

@@ -93,6 +93,40 @@ def test_tracker_loop_in_cpp_through_the_c_abi(tmp_path):
     import json
     j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert (n - 1) / j["track_secs"] > 150, j      # a floor for one cold run (1300-1370 frames/s warm: bench.py single_stream.device_chain)
+    # the look-ahead variant (frame k + 1 extracted beside the chain of frame k) returns the same record, byte for byte
+    out2 = subprocess.run([exe, "640", "480", str(n), str(tmp_path / "frames.raw"), str(tmp_path / "gt.bin"),
+                           *("%.17g" % v for v in K), str(tmp_path / "out_pf.bin"), "prefetch"], capture_output=True, text=True, timeout=300)
+    assert out2.returncode == 0, out2.stdout + out2.stderr
+    assert open(str(tmp_path / "out_pf.bin"), "rb").read()[:-8] == raw[:-8]      # (the file ends with the run's wall time)
+
+
+def test_tracker_lookahead_python_and_dropped_prefetch():
+    """Tracker.track(next_gray=...): identical results to the plain calls; a look-ahead that is not followed by its frame
+    (another buffer comes next, or a reset) is dropped without a trace"""
+    from orbslam_in_practice_amd import sequence as sq
+    frames, gt, K, _ = sq.make_plane_sequence(5, 5)
+    frames = [np.ascontiguousarray(f) for f in frames]
+    be = sq.TrackerBackend(1000, 640, 480)
+    r0 = be.track(frames[0], np.zeros(0, np.uint8), np.zeros((0, 3)), gt[0], K, 15.0)
+    n0 = len(r0["kps"])
+    fl = np.ones(n0, np.uint8) * 3
+    xw = np.random.default_rng(5).normal(size=(n0, 3)) + [0, 0, 4.0]
+    plain = be.track(frames[1], fl, xw, gt[1], K, 15.0)
+    be.reset()
+    be.track(frames[0], np.zeros(0, np.uint8), np.zeros((0, 3)), gt[0], K, 15.0, next_gray=frames[1])
+    ahead = be.track(frames[1], fl, xw, gt[1], K, 15.0, next_gray=frames[3])          # uses the look-ahead; fetches frame 3 ahead
+    for k in ("kps", "desc", "match", "outlier", "pose"):
+        assert np.array_equal(plain[k], ahead[k]), k
+    assert plain["n_matches"] == ahead["n_matches"] and plain["n_inliers"] == ahead["n_inliers"]
+    n1 = len(ahead["kps"])
+    r2a = be.track(frames[2], np.zeros(n1, np.uint8), np.zeros((n1, 3)), gt[2], K, 15.0)   # not frame 3: the look-ahead is dropped
+    be.reset()
+    be.track(frames[1], np.zeros(0, np.uint8), np.zeros((0, 3)), gt[1], K, 15.0, next_gray=frames[4])
+    be.reset()                                                                            # a reset drops it too
+    be.track(frames[1], np.zeros(0, np.uint8), np.zeros((0, 3)), gt[1], K, 15.0)
+    r2b = be.track(frames[2], np.zeros(n1, np.uint8), np.zeros((n1, 3)), gt[2], K, 15.0)
+    assert np.array_equal(r2a["kps"], r2b["kps"]) and np.array_equal(r2a["desc"], r2b["desc"])
+    be.close()
 
 
 def test_tracker_edge_cases():

@@ -19,9 +19,10 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 80
 frames, gt, K, _ = sq.make_plane_sequence(5, n)
 frames.tofile(td + "/f.raw")
 gt.astype(np.float64).tofile(td + "/gt.bin")
-for rep in range(3):
-    out = subprocess.run([exe, "640", "480", str(n), td + "/f.raw", td + "/gt.bin", *("%.17g" % v for v in K), td + "/out.bin"],
-                         capture_output=True, text=True)
-    print(out.stdout.strip().splitlines()[0] if out.stdout else "", out.stderr.strip()[-300:])
+for extra in ([], ["prefetch"]):
+    for rep in range(3):
+        out = subprocess.run([exe, "640", "480", str(n), td + "/f.raw", td + "/gt.bin", *("%.17g" % v for v in K), td + "/out.bin", *extra],
+                             capture_output=True, text=True)
+        print(" ".join(extra), out.stdout.strip().splitlines()[0] if out.stdout else "", out.stderr.strip()[-300:])
 rec = np.frombuffer(open(td + "/out.bin", "rb").read(), np.dtype([("pose", "<f8", 7), ("nm", "<i4"), ("inl", "<i4")]), n, 4)
 print("ATE %.4f m, mean matches %.0f, mean inliers %.0f" % (sq.ate_rmse(rec["pose"].copy(), gt), rec["nm"][1:].mean(), rec["inl"][1:].mean()))
