@@ -88,8 +88,8 @@ __device__ __forceinline__ void sincos_det(float angle, float *c_out, float *s_o
  *      identical lanes; here the 4 x SPW slots of the workgroup share one issue of them.
  *   3. (wavefront per slot) steered BRIEF: lane L evaluates bits L, L + 64, L + 128, L + 192; a ballot of each group
  *      is 8 descriptor bytes.
- * SPW = 16 for batches (the trig phase costs a sixty-fourth per keypoint), SPW = 1 for calls of a few frames, where
- * a frame's thousand keypoints must spread over the whole device rather than queue sixteen deep in 17 workgroups.
+ * SPW = 4 for batches (see launch_describe), SPW = 1 for calls of a few frames, where a frame's thousand keypoints
+ * must spread over the whole device rather than queue up in a few workgroups.
  * Integer moments are exact in any order and the float / double steps are the same functions on the same inputs:
  * bit-identical to the previous kernel and to the oracle. */
 typedef uint32_t u32_unaligned __attribute__((aligned(1)));
@@ -265,14 +265,22 @@ hipError_t orb_upload_constants(int device, hipStream_t stream) {
 hipError_t launch_describe(const OrbGeom &g, const OrbBuffers &b, int n_frames, OrbKeyPoint *d_kps, uint8_t *d_desc,
                            int cap, int32_t *d_counts, hipStream_t st) {
     static const int wide_min = getenv("ORBSLAM_AMD_DESC_BATCH_MIN") ? atoi(getenv("ORBSLAM_AMD_DESC_BATCH_MIN")) : 16;
-    if (n_frames >= wide_min) { /* 64 slots per workgroup: the trig phase is shared by 64 keypoints */
-        dim3 grid((g.total_out_cap + 63) / 64, n_frames);
-        hipLaunchKernelGGL(k_describe<16>, grid, dim3(256), 0, st, g, (const uint8_t *)b.pyr, (const uint8_t *)b.blur,
-                           (const uint32_t *)b.lvl_kp, (const int32_t *)b.lvl_cnt, d_kps, d_desc, cap, d_counts);
-    } else {
-        dim3 grid((g.total_out_cap + 3) / 4, n_frames);
-        hipLaunchKernelGGL(k_describe<1>, grid, dim3(256), 0, st, g, (const uint8_t *)b.pyr, (const uint8_t *)b.blur,
-                           (const uint32_t *)b.lvl_kp, (const int32_t *)b.lvl_cnt, d_kps, d_desc, cap, d_counts);
+    /* Slots per wavefront of a batch launch.  More slots share one issue of the trig phase (VALU instructions per 256
+       frames: 72 M at 2, 65 M at 4, 55 M at 8, 53 M at 16; 111 M for the wavefront-per-keypoint kernel), but fewer, longer
+       workgroups per frame put more FRAMES in flight on an XCD at once -- 256 resident workgroups are 15 frames at 16
+       slots, 4 at 4 -- and a frame's pyramids are 2 MB of a 4 MB L2: HBM-side fetch per launch 0.23 / 0.24 / 0.40 /
+       0.60 GB.  Throughput is the same within noise (156-157 k frames/s), so the default keeps the traffic down. */
+    static const int spw = getenv("ORBSLAM_AMD_DESC_SPW") ? atoi(getenv("ORBSLAM_AMD_DESC_SPW")) : 4;
+#define DESC_LAUNCH(SPW)                                                                                               \
+    {                                                                                                                  \
+        dim3 grid((g.total_out_cap + 4 * SPW - 1) / (4 * SPW), n_frames);                                              \
+        hipLaunchKernelGGL(k_describe<SPW>, grid, dim3(256), 0, st, g, (const uint8_t *)b.pyr, (const uint8_t *)b.blur, \
+                           (const uint32_t *)b.lvl_kp, (const int32_t *)b.lvl_cnt, d_kps, d_desc, cap, d_counts);      \
     }
+    if (n_frames < wide_min) DESC_LAUNCH(1)
+    else if (spw >= 16) DESC_LAUNCH(16)
+    else if (spw >= 8) DESC_LAUNCH(8)
+    else if (spw >= 4) DESC_LAUNCH(4)
+    else DESC_LAUNCH(2)
     return hipGetLastError();
 }

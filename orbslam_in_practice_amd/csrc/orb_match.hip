@@ -285,7 +285,6 @@ __global__ __launch_bounds__(256) void k_match_knn(MatchArgs A) {
  * k_match_knn<true>: the kept set is "the MK_TOP smallest of a set of unique keys", whatever the visiting order. */
 typedef int mm_v4i __attribute__((ext_vector_type(4)));
 typedef int mm_v16i __attribute__((ext_vector_type(16)));
-#define MM_CHUNK 128 /* F2 keypoints per LDS stage: 4 row tiles of 32, 8 KB of operand bytes each */
 __device__ __forceinline__ mm_v4i mm_bits01(uint32_t W, int h) {
     const uint32_t w = W >> (4 * h);
     mm_v4i r;
@@ -351,24 +350,29 @@ __device__ __forceinline__ void mm_merge_halves(uint32_t (&bk)[MK_TOP]) {
         bk[0] = key < bk[0] ? key : bk[0];
     }
 }
-template <int QB> /* query blocks of 32 per wavefront: 2 = fewer operand reads per pair, 1 = half the registers (4 waves per SIMD) */
+/* QB: query blocks of 32 per wavefront (2 = fewer operand reads per pair, 1 = half the registers: 4 waves per SIMD);
+   CH: F2 keypoints per LDS stage (8 KB of operand bytes per 32) -- the workgroups of this kernel sit beside the VALU-bound
+   kernels of the other lane for a long time, and what they hold in LDS those cannot use */
+template <int QB, int CH>
 __global__ __launch_bounds__(256) void k_match_knn_mfma(MatchArgs A) {
-    __shared__ mm_v4i s_a[(MM_CHUNK / 32) * 8 * 64];
-    __shared__ uint4 s_raw[MM_CHUNK * 2]; /* the same keypoints' descriptors as they are: a hit recomputes its distance from these */
-    __shared__ float s_x[MM_CHUNK], s_y[MM_CHUNK];
-    __shared__ uint32_t s_o[MM_CHUNK];
+    __shared__ mm_v4i s_a[(CH / 32) * 8 * 64];
+    __shared__ uint4 s_raw[CH * 2]; /* the same keypoints' descriptors as they are: a hit recomputes its distance from these */
+    __shared__ float s_x[CH], s_y[CH];
+    __shared__ uint32_t s_o[CH];
     const uint32_t KNONE = 0xFFFFFFFFu;
-    const int pair = blockIdx.y;
+    /* the query blocks of one pair read the same F2 set: they run on ONE XCD (consecutive remapped items share an L2) */
+    const int item = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int pair = item / (int)gridDim.x, qblk = item - pair * (int)gridDim.x;
     const int fa = A.pair_a ? A.pair_a[pair] : 2 * pair, fb = A.pair_b ? A.pair_b[pair] : 2 * pair + 1;
     const int n1 = A.counts[fa], n2 = A.counts[fb];
-    if ((int)(blockIdx.x * 128 * QB) >= n1) return; /* whole block beyond the query count (uniform) */
+    if (qblk * 128 * QB >= n1) return; /* whole block beyond the query count (uniform) */
     const OrbKeyPoint *k1 = A.kps + (size_t)fa * A.cap, *k2 = A.kps + (size_t)fb * A.cap;
     const uint8_t *D1 = A.desc + (size_t)fa * A.cap * 32, *D2 = A.desc + (size_t)fb * A.cap * 32;
     const bool brute = A.window < 0;
     const float invW = (float)GRID_COLS / (A.max_x - A.min_x), invH = (float)GRID_ROWS / (A.max_y - A.min_y);
     const float r = (float)A.window;
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
-    const int qbase = blockIdx.x * 128 * QB + (threadIdx.x >> 6) * 32 * QB;
+    const int qbase = qblk * 128 * QB + (threadIdx.x >> 6) * 32 * QB;
     /* the largest distance that can matter: d <= TH_LOW, or TH_LOW >= d * ratio (the exact test is repeated on a hit) */
     const float dq = A.nnratio > 0.0f ? (float)TH_LOW / A.nnratio : 1e9f;
     const int Dmax = dq >= 256.0f ? 256 : max(TH_LOW, (int)dq + 1);
@@ -425,9 +429,9 @@ __global__ __launch_bounds__(256) void k_match_knn_mfma(MatchArgs A) {
     float xn = 0.0f, yn = 0.0f;
 #define MM_FETCH(T0)                                                                                                   \
     {                                                                                                                  \
-        Wn = (T0) + ej < n2 ? ((const uint4 *)(D2 + (size_t)((T0) + ej) * 32))[eh] : make_uint4(0u, 0u, 0u, 0u);        \
+        Wn = (ej < CH && (T0) + ej < n2) ? ((const uint4 *)(D2 + (size_t)((T0) + ej) * 32))[eh] : make_uint4(0u, 0u, 0u, 0u);        \
         on = KNONE;                                                                                                    \
-        if (threadIdx.x < MM_CHUNK && (T0) + (int)threadIdx.x < n2) {                                                  \
+        if (threadIdx.x < CH && (T0) + (int)threadIdx.x < n2) {                                                  \
             const OrbKeyPoint kp_ = k2[(T0) + threadIdx.x];                                                            \
             const uint32_t ord_ = f2_order_key(kp_, (T0) + threadIdx.x, brute, A.min_x, A.min_y, invW, invH);          \
             if (ord_ != 0xFFFFFFFFu) on = brute ? ord_ : ((ord_ >> 16) << 11 | (ord_ & 0x7FFu)); /* cell << 11 | index */ \
@@ -436,16 +440,17 @@ __global__ __launch_bounds__(256) void k_match_knn_mfma(MatchArgs A) {
         }                                                                                                              \
     }
     if (any_active && n2 > 0) MM_FETCH(0)
-    for (int t0 = 0; any_active && t0 < n2; t0 += MM_CHUNK) {
-        const int nt = min(MM_CHUNK, n2 - t0);
+    for (int t0 = 0; any_active && t0 < n2; t0 += CH) {
+        const int nt = min(CH, n2 - t0);
         __syncthreads(); /* the previous chunk has been consumed */
-        if (threadIdx.x < MM_CHUNK) {
+        if (threadIdx.x < CH) {
             s_o[threadIdx.x] = on;
             s_x[threadIdx.x] = xn;
             s_y[threadIdx.x] = yn;
         }
         {
             const int base = ((ej >> 5) * 8 + 4 * eh) * 64 + (ej & 31); /* tile ej / 32, K-step 4 eh + k, row ej % 32 */
+            if (ej < CH) {
             s_raw[threadIdx.x] = Wn;
             s_a[base] = mm_bits01(Wn.x, 0);
             s_a[base + 32] = mm_bits01(Wn.x, 1);
@@ -455,9 +460,10 @@ __global__ __launch_bounds__(256) void k_match_knn_mfma(MatchArgs A) {
             s_a[base + 160] = mm_bits01(Wn.z, 1);
             s_a[base + 192] = mm_bits01(Wn.w, 0);
             s_a[base + 224] = mm_bits01(Wn.w, 1);
+            }
         }
         __syncthreads();
-        if (t0 + MM_CHUNK < n2) MM_FETCH(t0 + MM_CHUNK)
+        if (t0 + CH < n2) MM_FETCH(t0 + CH)
         const int ntile = (nt + 31) >> 5;
         for (int tile = 0; tile < ntile; tile++) {
             mm_v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
@@ -1201,7 +1207,11 @@ static size_t match_lds_bytes(int cap) { return (((size_t)cap * 27 + 15) & ~(siz
 static int launch_match(const MatchArgs &A_in, int n_pairs, hipStream_t st, hipEvent_t mid = nullptr) {
     MatchArgs A = A_in;
     size_t lds = match_lds_bytes(A.cap);
-    A.desc_in_lds = (lds + (size_t)A.cap * 32 <= 96 * 1024) ? 1 : 0; /* keeps >= 1 workgroup per CU resident */
+    /* F2 descriptors LDS-resident for the (rare) rescans: worth it for a call of a few pairs (latency); in a batch the 256
+       single-wavefront workgroups would each hold another 32 KB of their CU's LDS for the length of the serial walk, which
+       the VALU-bound kernels of the other lane then cannot use (160.5 k -> 163 k frames/s without) */
+    static const int desc_lds_max = getenv("ORBSLAM_AMD_MATCH_DESC_LDS") ? atoi(getenv("ORBSLAM_AMD_MATCH_DESC_LDS")) : 8;
+    A.desc_in_lds = (n_pairs <= desc_lds_max && lds + (size_t)A.cap * 32 <= 96 * 1024) ? 1 : 0;
     if (A.desc_in_lds) lds += (size_t)A.cap * 32;
     if (lds > 160 * 1024 - 1024) {
         m_err = "matcher: keypoint capacity too large for the LDS-resident frame state";
@@ -1211,10 +1221,16 @@ static int launch_match(const MatchArgs &A_in, int n_pairs, hipStream_t st, hipE
     MCHK(lim.ensure((const void *)k_match_init, lds));
     static const int no_mfma = getenv("ORBSLAM_AMD_MATCH_NO_MFMA") ? 1 : 0; /* diagnostics: the xor / popcount scan */
     static const int mfma_qb = getenv("ORBSLAM_AMD_MATCH_QB") ? atoi(getenv("ORBSLAM_AMD_MATCH_QB")) : 1;
-    if (A.cap <= (A.window < 0 ? 65536 : 2048) && !no_mfma && mfma_qb == 1)
-        hipLaunchKernelGGL(k_match_knn_mfma<1>, dim3((A.cap + 127) / 128, n_pairs), dim3(256), 0, st, A);
-    else if (A.cap <= (A.window < 0 ? 65536 : 2048) && !no_mfma)
-        hipLaunchKernelGGL(k_match_knn_mfma<2>, dim3((A.cap + 255) / 256, n_pairs), dim3(256), 0, st, A);
+    static const int mfma_ch = getenv("ORBSLAM_AMD_MATCH_CHUNK") ? atoi(getenv("ORBSLAM_AMD_MATCH_CHUNK")) : 32;
+    const bool key32 = A.cap <= (A.window < 0 ? 65536 : 2048);
+    if (key32 && !no_mfma && mfma_qb == 1 && mfma_ch <= 32)
+        hipLaunchKernelGGL((k_match_knn_mfma<1, 32>), dim3((A.cap + 127) / 128, n_pairs), dim3(256), 0, st, A);
+    else if (key32 && !no_mfma && mfma_qb == 1 && mfma_ch <= 64)
+        hipLaunchKernelGGL((k_match_knn_mfma<1, 64>), dim3((A.cap + 127) / 128, n_pairs), dim3(256), 0, st, A);
+    else if (key32 && !no_mfma && mfma_qb == 1)
+        hipLaunchKernelGGL((k_match_knn_mfma<1, 128>), dim3((A.cap + 127) / 128, n_pairs), dim3(256), 0, st, A);
+    else if (key32 && !no_mfma)
+        hipLaunchKernelGGL((k_match_knn_mfma<2, 128>), dim3((A.cap + 255) / 256, n_pairs), dim3(256), 0, st, A);
     else if (A.cap <= (A.window < 0 ? 65536 : 2048))
         hipLaunchKernelGGL(k_match_knn<true>, dim3((A.cap + 255) / 256, n_pairs), dim3(256), 0, st, A);
     else

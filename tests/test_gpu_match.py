@@ -108,6 +108,45 @@ def test_search_for_initialization_contention(oracle, n1, n2, nproto, flip, wind
     m.close()
 
 
+@pytest.mark.parametrize("n1,n2,ratio,window", [(33, 129, 0.9, -1), (257, 31, 0.05, -1), (1, 1000, 0.9, -1), (1000, 1, 2.5, -1),
+                                                 (130, 127, 1.0, 60), (513, 511, 0.3, -1), (96, 160, 0.9, 25), (640, 383, 0.75, 200)])
+def test_search_for_initialization_matrix_core_edges(oracle, n1, n2, ratio, window):
+    """The matrix-core phase 1 (k_match_knn_mfma) at its edges: set sizes that end inside a 32-row tile / a 128-keypoint
+    stage / a 32-query block, ratios from 'every distance matters' (0.05: the threshold saturates at 256 and EVERY pair
+    takes the hit path) to 'nothing beyond TH_LOW matters' (2.5), descriptors with no bit or every bit set (popcount 0 /
+    256: the per-query threshold at its extremes), exact duplicates (more than eight candidates at distance 0: the key
+    lists overflow and only the order key decides), small windows."""
+    import orbslam_in_practice_amd as oa
+    rng = np.random.default_rng(n1 * 131 + n2 * 7 + int(ratio * 100))
+    base = rng.integers(0, 256, (12, 32), dtype=np.uint8)
+    base[0] = 0
+    base[1] = 255
+
+    def descs(n):
+        d = base[rng.integers(0, len(base), n)].copy()
+        noisy = rng.random(n) < 0.7
+        for i in np.nonzero(noisy)[0]:
+            for b in rng.integers(0, 256, rng.integers(1, 40)):
+                d[i, b >> 3] ^= np.uint8(1 << (b & 7))
+        return d
+
+    def kps(n):
+        kp = np.zeros(n, oa.KP_DTYPE)
+        kp["x"], kp["y"] = rng.uniform(20, 620, n), rng.uniform(20, 460, n)
+        kp["angle"] = rng.uniform(0, 360, n)
+        kp["octave"] = rng.integers(0, 2, n) if window >= 0 else 0
+        return kp
+
+    b = (0.0, 640.0, 0.0, 480.0)
+    k1, k2, d1, d2 = kps(n1), kps(n2), descs(n1), descs(n2)
+    m = oa.ORBmatcher(ratio, True, max_keypoints=2048)
+    prev = np.stack([k1["x"], k1["y"]], axis=1).astype(np.float32).copy()
+    on, om12, opm = oracle.search_for_initialization(k1, d1, k2, d2, b, prev.copy(), window, ratio, True)
+    gn, gm12 = m.SearchForInitialization(oa.FrameFeatures(k1, d1, b), oa.FrameFeatures(k2, d2, b), prev, window)
+    assert gn == on and np.array_equal(gm12, om12) and np.array_equal(prev, opm)
+    m.close()
+
+
 def test_features_in_area_device(oracle, feats):
     """the device GetFeaturesInArea (grid-free, rank-ordered) returns what the oracle's 64x48-cell
     FrameGrid walk returns, index for index, for windows inside, across and outside the image and every level filter"""
