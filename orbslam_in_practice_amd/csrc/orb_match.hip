@@ -1,14 +1,19 @@
 /*
- * orb_match.hip -- ORBmatcher on gfx950: Hamming distances with v_xor / v_bcnt (popcount) and
- * wavefront min-reductions.
+ * orb_match.hip -- ORBmatcher on gfx950: all-pairs Hamming distances as i8 MFMA products (xor / popcount
+ * scans as the fallback), wavefront min-reductions, speculative rounds for the sequential walks.
  *
  *   k_hamming_knn2   brute-force 2-NN (north_star / SURVEY a12): one query descriptor per lane in
  *                    8 VGPRs, the train set streamed through LDS in 1024-descriptor tiles and read
  *                    back as wave-wide broadcasts (conflict free), ties -> lowest index.
+ *   k_hamming_knn2_mfma  the same result from an i8 MFMA product (see k_match_knn_mfma): the default.
  *   k_match_knn      phase 1 of ORBmatcher::SearchForInitialization (reference src/ORBmatcher.cpp:9-126
  *                    with Frame::GetFeaturesInArea, src/Frame.cpp:219-271): fully parallel, the 8
  *                    smallest (distance, grid order, index) keys of every query over all its window
  *                    candidates, ignoring the greedy filter.
+ *   k_match_knn_mfma phase 1 on the matrix cores: all-pairs Hamming distance as a matrix product of
+ *                    0/1 and +-1 operand bytes (v_mfma_i32_32x32x32_i8), branch-free scan of the
+ *                    results against the largest distance that can matter; the default when the
+ *                    32-bit key fits (k_match_knn otherwise).
  *   k_match_init     phase 2: ONE wavefront per frame pair.  The reference loop over i1 carries a
  *                    dependency (a later i1 may only take an i2 whose recorded match distance is
  *                    larger, :49-50); the filtered candidate set is a subset of the unfiltered one, so
@@ -497,6 +502,69 @@ __global__ __launch_bounds__(256) void k_match_knn_mfma(MatchArgs A) {
 #pragma unroll
         for (int k = 0; k < MK_TOP / 2; k++)
             A.knn[((size_t)pair * A.cap + i1) * (MK_TOP / 2) + k] = make_ulonglong2(out[2 * k], out[2 * k + 1]);
+    }
+}
+
+/* The plain brute-force 2-NN primitive on the matrix cores (n2 <= 65536; k_hamming_knn2 beyond): the products of
+ * k_match_knn_mfma, but EVERY distance matters, so each result becomes a key (d << 16 | j) -- one v_lshl_add and one
+ * add of the register's row constant -- and goes through a two-entry sorted insert (v_min + v_med3): 4 VALU
+ * instructions per distance-lane where xor / popcount / compare took ~21.  Ties resolve to the lowest index because
+ * the index is the low half of the key; the second-best DISTANCE is the distance of the second-smallest key (duplicates
+ * count), exactly what the sequential scan keeps.  32 queries per wavefront, 128 per workgroup, F2 in 32-row stages. */
+__global__ __launch_bounds__(256) void k_hamming_knn2_mfma(const uint8_t *d1, int n1, const uint8_t *d2, int n2, int32_t *idx,
+                                                            uint16_t *best, uint16_t *second) {
+    __shared__ mm_v4i s_a[8 * 64];
+    const uint32_t KNONE = 0xFFFFFFFFu;
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    const int qi = blockIdx.x * 128 + (threadIdx.x >> 6) * 32 + c;
+    uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (qi < n1) {
+        const uint4 *p = (const uint4 *)(d1 + (size_t)qi * 32);
+        const uint4 v0 = p[0], v1 = p[1];
+        w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w;
+        w[4] = v1.x; w[5] = v1.y; w[6] = v1.z; w[7] = v1.w;
+    }
+    mm_v4i bq[8];
+    int pq = 0;
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        pq += __popc(w[s]);
+        bq[s] = mm_bits_pm(w[s], h);
+    }
+    uint32_t b1 = KNONE, b2 = KNONE;
+    const int ej = threadIdx.x >> 3, es = threadIdx.x & 7; /* staging: word es of F2 descriptor ej of the stage */
+    uint32_t Wn = (n2 > 0 && ej < n2) ? ((const uint32_t *)(d2 + (size_t)ej * 32))[es] : 0u;
+    for (int t0 = 0; t0 < n2; t0 += 32) {
+        __syncthreads(); /* the previous stage has been consumed */
+        s_a[es * 64 + ej] = mm_bits01(Wn, 0);
+        s_a[es * 64 + 32 + ej] = mm_bits01(Wn, 1);
+        __syncthreads();
+        Wn = (t0 + 32 + ej < n2) ? ((const uint32_t *)(d2 + (size_t)(t0 + 32 + ej) * 32))[es] : 0u;
+        mm_v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 8; s++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(s_a[s * 64 + lane], bq[s], acc, 0, 0, 0);
+        const uint32_t cb = ((uint32_t)pq << 16) + (uint32_t)(t0 + 4 * h); /* (pq + result) << 16 | F2 index of row 4 h */
+        const bool tail = t0 + 32 > n2; /* rows beyond the set (zero operands): their keys are dropped */
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int row = (i & 3) + 8 * (i >> 2); /* C/D row of register i, minus 4 h */
+            uint32_t key = ((uint32_t)acc[i] << 16) + cb + (uint32_t)row;
+            if (tail && t0 + 4 * h + row >= n2) key = KNONE;
+            b2 = umed3(b1, b2, key);
+            b1 = key < b1 ? key : b1;
+        }
+    }
+    { /* lanes c and c + 32 saw the two halves of the rows */
+        const uint32_t o1 = (uint32_t)__shfl_xor((int)b1, 32), o2 = (uint32_t)__shfl_xor((int)b2, 32);
+        b2 = umed3(b1, b2, o1);
+        b1 = o1 < b1 ? o1 : b1;
+        b2 = umed3(b1, b2, o2);
+        b1 = o2 < b1 ? o2 : b1;
+    }
+    if (qi < n1 && h == 0) {
+        idx[qi] = b1 == KNONE ? -1 : (int32_t)(b1 & 0xFFFFu);
+        best[qi] = (uint16_t)(b1 == KNONE ? 0xFFFFu : b1 >> 16);
+        second[qi] = (uint16_t)(b2 == KNONE ? 0xFFFFu : b2 >> 16);
     }
 }
 
@@ -1192,8 +1260,13 @@ extern "C" int orb_hamming_knn2(OrbMatcher *m, const uint8_t *d1, int n1, const 
     MCHK(hipMemcpyAsync(m->d_desc, d1, (size_t)n1 * 32, hipMemcpyHostToDevice, m->stream));
     if (n2 > 0)
         MCHK(hipMemcpyAsync(m->d_desc + (size_t)m->max_kp * 32, d2, (size_t)n2 * 32, hipMemcpyHostToDevice, m->stream));
-    hipLaunchKernelGGL(k_hamming_knn2, dim3((n1 + 255) / 256), dim3(256), 0, m->stream, (const uint8_t *)m->d_desc, n1,
-                       (const uint8_t *)(m->d_desc + (size_t)m->max_kp * 32), n2, m->d_idx, m->d_best, m->d_second);
+    static const int knn2_no_mfma = getenv("ORBSLAM_AMD_MATCH_NO_MFMA") ? 1 : 0;
+    if (n2 <= 65536 && !knn2_no_mfma)
+        hipLaunchKernelGGL(k_hamming_knn2_mfma, dim3((n1 + 127) / 128), dim3(256), 0, m->stream, (const uint8_t *)m->d_desc, n1,
+                           (const uint8_t *)(m->d_desc + (size_t)m->max_kp * 32), n2, m->d_idx, m->d_best, m->d_second);
+    else
+        hipLaunchKernelGGL(k_hamming_knn2, dim3((n1 + 255) / 256), dim3(256), 0, m->stream, (const uint8_t *)m->d_desc, n1,
+                           (const uint8_t *)(m->d_desc + (size_t)m->max_kp * 32), n2, m->d_idx, m->d_best, m->d_second);
     MCHK(hipGetLastError());
     MCHK(hipMemcpyAsync(idx, m->d_idx, (size_t)n1 * 4, hipMemcpyDeviceToHost, m->stream));
     MCHK(hipMemcpyAsync(best, m->d_best, (size_t)n1 * 2, hipMemcpyDeviceToHost, m->stream));

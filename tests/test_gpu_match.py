@@ -21,7 +21,8 @@ def matcher():
 
 def test_knn2_random(matcher, oracle):
     from orbslam_in_practice_amd import synth
-    for (n1, n2, seed) in [(1000, 1000, 1), (257, 2049, 2), (1, 1, 3), (64, 3, 4), (5, 0, 5)]:
+    for (n1, n2, seed) in [(1000, 1000, 1), (257, 2049, 2), (1, 1, 3), (64, 3, 4), (5, 0, 5), (129, 33, 6), (40, 31, 7), (300, 4000, 8),
+                           (2, 2, 9), (128, 32, 10), (33, 1, 11)]:
         d1, d2 = synth.random_descriptors(seed, n1), synth.random_descriptors(seed + 100, n2)
         if n2 > 2:
             d2[1] = d2[0]          # duplicate rows: tie -> lowest index, second == best
