@@ -1503,17 +1503,47 @@ __device__ __noinline__ void ba_schur_lists(const BAWin &w, double *D, const int
        contribution list (edge pairs of the points both cameras see) with W and Dinv gathered from memory --
        a single window's 8 MB stay in L2 / Infinity Cache.  Four blocks per wavefront, the edge ids of the NEXT
        contribution fetched ahead of the operand loads of the current one. ---- */
-    for (int u0 = gwave * 4; u0 < w.nub; u0 += gwaves * 4) {
-        const int sub = lane >> 4, l16 = lane & 15;
-        const int bk = (u0 + sub < w.nub) ? I[w.blk_upper + u0 + sub] : w.nnzb; /* upper blocks only */
+    /* The index chain of a block -- blk_upper -> con_start -> con_e1 / con_e2 -> pt -- is four dependent memory round
+       trips before the first operand load, and one window in flight has nothing else to hide them behind: they are
+       walked for SL_R rounds at once (independent loads side by side), so a round pays one round trip for its operands
+       and a quarter of the chain.  The update of S is spread over the group's 16 lanes (2-3 entries each, loads in
+       parallel) instead of 36 dependent read-modify-writes on one lane. */
+    constexpr int SL_R = 4;
+    const int sub = lane >> 4, l16 = lane & 15;
+    for (int ub = gwave * 4; ub < w.nub; ub += gwaves * 4 * SL_R) {
+        int bkr[SL_R], k1r[SL_R], kqr[SL_R], e1r[SL_R], e2r[SL_R], ppr[SL_R];
+#pragma unroll
+        for (int r = 0; r < SL_R; r++) {
+            const int u = ub + r * gwaves * 4 + sub;
+            bkr[r] = u < w.nub ? I[w.blk_upper + u] : w.nnzb; /* upper blocks only */
+        }
+#pragma unroll
+        for (int r = 0; r < SL_R; r++) {
+            const bool on = bkr[r] < w.nnzb;
+            const int k0 = on ? I[w.con_start + bkr[r]] : 0;
+            k1r[r] = on ? I[w.con_start + bkr[r] + 1] : 0;
+            kqr[r] = k0 + l16;
+        }
+#pragma unroll
+        for (int r = 0; r < SL_R; r++) {
+            const bool on = kqr[r] < k1r[r];
+            e1r[r] = on ? I[w.con_e1 + kqr[r]] : 0;
+            e2r[r] = on ? I[w.con_e2 + kqr[r]] : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < SL_R; r++) ppr[r] = kqr[r] < k1r[r] ? I[w.pt + e1r[r]] : 0;
+#pragma unroll
+        for (int r = 0; r < SL_R; r++) {
+        if (ub + r * gwaves * 4 >= w.nub) break; /* uniform */
+        const int bk = bkr[r];
         double acc[36];
 #pragma unroll
         for (int i = 0; i < 36; i++) acc[i] = 0.0;
         if (bk < w.nnzb) {
-            const int k0 = I[w.con_start + bk], k1 = I[w.con_start + bk + 1];
-            int kq = k0 + l16;
-            int e1n = kq < k1 ? I[w.con_e1 + kq] : 0, e2n = kq < k1 ? I[w.con_e2 + kq] : 0;
-            int pn = kq < k1 ? I[w.pt + e1n] : 0;
+            const int k1 = k1r[r];
+            const int kq = kqr[r];
+            int e1n = e1r[r], e2n = e2r[r];
+            int pn = ppr[r];
             for (int k = kq; k < k1; k += 16) {
                 const int e1 = e1n, e2 = e2n, pp = pn;
                 if (k + 16 < k1) {
@@ -1536,16 +1566,16 @@ __device__ __noinline__ void ba_schur_lists(const BAWin &w, double *D, const int
                 }
                 double y[18];
 #pragma unroll
-                for (int r = 0; r < 6; r++) {
-                    y[r * 3] = w1[r * 3] * iv[0] + w1[r * 3 + 1] * iv[3] + w1[r * 3 + 2] * iv[6];
-                    y[r * 3 + 1] = w1[r * 3] * iv[1] + w1[r * 3 + 1] * iv[4] + w1[r * 3 + 2] * iv[7];
-                    y[r * 3 + 2] = w1[r * 3] * iv[2] + w1[r * 3 + 1] * iv[5] + w1[r * 3 + 2] * iv[8];
+                for (int rr = 0; rr < 6; rr++) {
+                    y[rr * 3] = w1[rr * 3] * iv[0] + w1[rr * 3 + 1] * iv[3] + w1[rr * 3 + 2] * iv[6];
+                    y[rr * 3 + 1] = w1[rr * 3] * iv[1] + w1[rr * 3 + 1] * iv[4] + w1[rr * 3 + 2] * iv[7];
+                    y[rr * 3 + 2] = w1[rr * 3] * iv[2] + w1[rr * 3 + 1] * iv[5] + w1[rr * 3 + 2] * iv[8];
                 }
 #pragma unroll
-                for (int r = 0; r < 6; r++)
+                for (int rr = 0; rr < 6; rr++)
 #pragma unroll
                     for (int c = 0; c < 6; c++)
-                        acc[r * 6 + c] += y[r * 3] * ww[c * 3] + y[r * 3 + 1] * ww[c * 3 + 1] + y[r * 3 + 2] * ww[c * 3 + 2];
+                        acc[rr * 6 + c] += y[rr * 3] * ww[c * 3] + y[rr * 3 + 1] * ww[c * 3 + 1] + y[rr * 3 + 2] * ww[c * 3 + 2];
             }
         }
 #pragma unroll
@@ -1555,9 +1585,16 @@ __device__ __noinline__ void ba_schur_lists(const BAWin &w, double *D, const int
             for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
             acc[i] = v;
         }
-        if (l16 == 0 && bk < w.nnzb) {
-#pragma unroll
-            for (int i = 0; i < 36; i++) D[w.S + (int64_t)bk * 36 + i] -= acc[i]; /* sole owner: no race */
+        if (bk < w.nnzb) { /* sole owner group: no race; every lane of the group holds all 36 sums */
+            double *Sb = D + w.S + (int64_t)bk * 36;
+            const double a0 = l16 == 0 ? acc[0] : l16 == 1 ? acc[1] : l16 == 2 ? acc[2] : l16 == 3 ? acc[3] : l16 == 4 ? acc[4] : l16 == 5 ? acc[5] : l16 == 6 ? acc[6] : l16 == 7 ? acc[7] : l16 == 8 ? acc[8] : l16 == 9 ? acc[9] : l16 == 10 ? acc[10] : l16 == 11 ? acc[11] : l16 == 12 ? acc[12] : l16 == 13 ? acc[13] : l16 == 14 ? acc[14] : acc[15];
+            const double a1 = l16 == 0 ? acc[16] : l16 == 1 ? acc[17] : l16 == 2 ? acc[18] : l16 == 3 ? acc[19] : l16 == 4 ? acc[20] : l16 == 5 ? acc[21] : l16 == 6 ? acc[22] : l16 == 7 ? acc[23] : l16 == 8 ? acc[24] : l16 == 9 ? acc[25] : l16 == 10 ? acc[26] : l16 == 11 ? acc[27] : l16 == 12 ? acc[28] : l16 == 13 ? acc[29] : l16 == 14 ? acc[30] : acc[31];
+            const double a2 = l16 == 0 ? acc[32] : l16 == 1 ? acc[33] : l16 == 2 ? acc[34] : acc[35];
+            const double s0 = Sb[l16], s1 = Sb[16 + l16], s2 = l16 < 4 ? Sb[32 + l16] : 0.0;
+            Sb[l16] = s0 - a0;
+            Sb[16 + l16] = s1 - a1;
+            if (l16 < 4) Sb[32 + l16] = s2 - a2;
+        }
         }
     }
 }
@@ -1569,20 +1606,31 @@ __device__ __noinline__ void ba_g_lists(const BAWin &w, double *D, const int32_t
         const int cam = I[w.blk_row + w.Ncf + 1 + sl]; /* slot -> camera (stored behind the row starts) */
         const int k0 = I[w.cam_start + cam], k1 = I[w.cam_start + cam + 1];
         double acc[6] = {0, 0, 0, 0, 0, 0};
-        for (int k = k0 + lane; k < k1; k += 64) {
-            const int e = I[w.cam_edges + k];
-            const double2 *We = (const double2 *)(D + w.W + (int64_t)e * 18);
-            const double *tp = D + w.tv + (int64_t)I[w.pt + e] * 3;
-            const double b0 = tp[0], b1 = tp[1], b2 = tp[2];
-            double y[18];
+        /* edge id -> point id -> operands are three dependent round trips per step: the ids of GL_U steps are fetched side
+           by side first, so that a step waits for its operands only */
+        constexpr int GL_U = 4;
+        for (int kb = k0 + lane; kb < k1; kb += 64 * GL_U) {
+            int eu[GL_U], pu[GL_U];
 #pragma unroll
-            for (int i = 0; i < 9; i++) {
-                const double2 t = We[i];
-                y[2 * i] = t.x;
-                y[2 * i + 1] = t.y;
+            for (int u = 0; u < GL_U; u++) eu[u] = kb + 64 * u < k1 ? I[w.cam_edges + kb + 64 * u] : -1;
+#pragma unroll
+            for (int u = 0; u < GL_U; u++) pu[u] = eu[u] >= 0 ? I[w.pt + eu[u]] : 0;
+#pragma unroll
+            for (int u = 0; u < GL_U; u++) {
+                if (eu[u] < 0) continue;
+                const double2 *We = (const double2 *)(D + w.W + (int64_t)eu[u] * 18);
+                const double *tp = D + w.tv + (int64_t)pu[u] * 3;
+                const double b0 = tp[0], b1 = tp[1], b2 = tp[2];
+                double y[18];
+#pragma unroll
+                for (int i = 0; i < 9; i++) {
+                    const double2 t = We[i];
+                    y[2 * i] = t.x;
+                    y[2 * i + 1] = t.y;
+                }
+#pragma unroll
+                for (int a = 0; a < 6; a++) acc[a] += y[a * 3] * b0 + y[a * 3 + 1] * b1 + y[a * 3 + 2] * b2;
             }
-#pragma unroll
-            for (int a = 0; a < 6; a++) acc[a] += y[a * 3] * b0 + y[a * 3 + 1] * b1 + y[a * 3 + 2] * b2;
         }
 #pragma unroll
         for (int a = 0; a < 6; a++) {
