@@ -1960,8 +1960,18 @@ __device__ __forceinline__ double ba_phase_backsub(const BAWin &w, double *D, co
     for (int p = gtid; p < w.Np; p += gthreads) {
         double cl[3] = {D[w.bl + (int64_t)p * 3], D[w.bl + (int64_t)p * 3 + 1], D[w.bl + (int64_t)p * 3 + 2]};
         const int e0 = I[w.pt_start + p], e1 = I[w.pt_start + p + 1];
-        for (int e = e0; e < e1; e++) {
-            const int c = I[w.cam + e], sl = I[w.slot + c];
+        /* camera id -> slot -> operands: three dependent round trips per edge; the two index levels of BS_U edges go out
+           side by side (a point has ~6 edges: two groups instead of a dozen dependent index loads) */
+        constexpr int BS_U = 4;
+        for (int eb = e0; eb < e1; eb += BS_U) {
+            int cu[BS_U], su[BS_U];
+#pragma unroll
+            for (int u = 0; u < BS_U; u++) cu[u] = eb + u < e1 ? I[w.cam + eb + u] : -1;
+#pragma unroll
+            for (int u = 0; u < BS_U; u++) su[u] = cu[u] >= 0 ? I[w.slot + cu[u]] : -1;
+#pragma unroll
+            for (int u = 0; u < BS_U; u++) {
+            const int e = eb + u, c = cu[u], sl = su[u];
             if (sl < 0) continue;
             const double *xc = D + w.x + sl * 6;
             if (COMPACT) {
@@ -1976,6 +1986,7 @@ __device__ __forceinline__ double ba_phase_backsub(const BAWin &w, double *D, co
                 const double *We = D + w.W + (int64_t)e * 18;
                 for (int bb = 0; bb < 3; bb++)
                     for (int a = 0; a < 6; a++) cl[bb] -= We[a * 3 + bb] * xc[a];
+            }
             }
         }
         double vv[3];
