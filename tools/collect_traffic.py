@@ -37,10 +37,23 @@ def load(d, counter):
     f = (glob.glob(d + "/*counter_collection.csv") + glob.glob(d + "/*/*counter_collection.csv"))[0]
     tot = collections.defaultdict(float)
     calls = collections.Counter()
-    for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] != counter:
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+    # The profiled command is the whole bench line, whose one-stream legs launch the SAME front-end kernels on single
+    # frames: only the batch launches are tallied (a dispatch counts when its grid is within 1/32 of the largest grid of
+    # its kernel -- the smallest pyramid level of a batch is still 40 x the largest level of one frame, a one-frame quadtree
+    # launch 1/64 of a batch's).  Until late
+    # round 3 the single-frame launches were counted as launches too, which diluted every per-launch figure of the
+    # front-end by the share of those launches (x 0.78 with 46 tracked frames next to 160 batch launches).
+    gmax = collections.defaultdict(int)
+
+    def kname(r):
+        return r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+    for r in rows:
+        gmax[kname(r)] = max(gmax[kname(r)], int(r["Grid_Size"]))
+    for r in rows:
+        name = kname(r)
+        if name in STAGE and not name.startswith("k_ba") and int(r["Grid_Size"]) * 32 < gmax[name]:
             continue
-        name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
         if name == "k_match_knn_mfma":  # phase 1 of the matcher on the matrix cores: same stage as k_match_knn
             name = "k_match_knn"
         if name == "k_ba_iteration" and int(r["Grid_Size"]) != BA_BATCH * 512:
