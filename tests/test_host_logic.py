@@ -107,3 +107,39 @@ def test_traffic_figures_are_dropped_when_a_kernel_source_changed(tmp_path, monk
 def test_committed_traffic_file_is_stamped():
     tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     assert "_src_sha16" in tj and "_collected" in tj
+
+
+def test_traffic_tally_counts_batch_launches_only(tmp_path):
+    """tools/collect_traffic.py: the profiled bench line launches the front-end kernels on single frames too (its one-stream
+    legs); those dispatches must not count as launches of the batch stages (they diluted every per-launch figure by their
+    share until late round 3).  A synthetic counter file: 4 batch launches and 6 one-frame launches of FAST, resizes of two
+    levels, one BA round."""
+    import subprocess
+    hdr = "Correlation_Id,Dispatch_Id,Agent_Id,Queue_Id,Process_Id,Thread_Id,Grid_Size,Kernel_Id,Kernel_Name,Workgroup_Size,LDS_Block_Size,Scratch_Size,VGPR_Count,Accum_VGPR_Count,SGPR_Count,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp"
+    rows = []
+
+    def add(name, grid, val, counter):
+        rows.append("1,%d,1,1,1,1,%d,1,\"%s\",64,0,0,32,0,32,%s,%g,0,1" % (len(rows) + 1, grid, name, counter, val))
+    for counter, unit in (("FETCH_SIZE", 1000.0), ("WRITE_SIZE", 500.0)):
+        rows.clear()
+        for _ in range(4):
+            add("k_fast_cells_wave(OrbGeom)", 815 * 256 * 64, unit, counter)          # a batch of 256 frames
+            add("k_copy_level0(OrbGeom)", 150 * 256 * 256, unit, counter)
+            add("k_resize(OrbGeom)", 65 * 256 * 256, unit, counter)                   # level 1 of the batch
+            add("k_resize(OrbGeom)", 10 * 256 * 256, unit, counter)                   # level 7 of the batch: still a batch launch
+        for _ in range(6):
+            add("k_fast_cells_wave(OrbGeom)", 815 * 64, unit / 256, counter)           # one frame (tracking loop)
+            add("k_copy_level0(OrbGeom)", 150 * 256, unit / 256, counter)
+            add("k_resize(OrbGeom)", 65 * 256, unit / 256, counter)
+        add("k_ba_ph_hll(BABufs)", 256 * 256, 7 * unit, counter)
+        add("k_ba_ph_round(BABufs,int,int)", 256, 0.0, counter)
+        d = tmp_path / ("pmc_" + counter)
+        d.mkdir()
+        (d / "1_counter_collection.csv").write_text(hdr + "\n" + "\n".join(rows) + "\n")
+    out = tmp_path / "traffic.json"
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "collect_traffic.py"), str(tmp_path / "pmc_FETCH_SIZE"),
+                    str(tmp_path / "pmc_WRITE_SIZE"), str(out), "256"], check=True, capture_output=True)
+    tj = json.load(open(out))
+    assert tj["fast"] == int(1000.0 * 1024 * 2 + 500.0 * 1024)                    # per batch launch: fetch doubled (gfx950) + write
+    assert tj["pyramid"] == int(3 * (1000.0 * 1024 * 2 + 500.0 * 1024))           # copy + two resize levels, per batch launch
+    assert tj["ba_iteration"] == int(7 * (1000.0 * 1024 * 2 + 500.0 * 1024))
