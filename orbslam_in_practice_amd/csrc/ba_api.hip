@@ -4670,29 +4670,27 @@ extern "C" int ba_pose_optimization_batch(BASolver *s, double *poses, const doub
         if (offsets[p + 1] < offsets[p]) return ORB_E_INVALID;
     BCHK(hipSetDevice(s->device));
     int rc;
-    const size_t nd = (size_t)n_problems * 7 + (size_t)n * 6 + 8, nb = (size_t)n * 2 + 16;
+    /* ONE device block and its pinned mirror, laid out so that the inputs go up in one copy and the outputs come back in one
+       (six small copies cost ~8 us of host time each, and Tracking calls this up to three times per frame):
+         [ xw 3n | obs 2n | info n | offsets (int32) | poses 7p ]   <- upload
+                                               [ poses 7p | n_inliers (int32) | outlier (bytes) ]   <- download */
+    const size_t npose = ((size_t)n_problems * 7 + 1) & ~(size_t)1, noffs = ((size_t)n_problems + 2) / 2, nninl = ((size_t)n_problems + 1) / 2,
+                 nout = ((size_t)n + 7) / 8;
+    const size_t o_offs = (size_t)n * 6, o_pose = o_offs + noffs, o_ninl = o_pose + npose, o_out = o_ninl + nninl, nd = o_out + nout + 2;
     if ((rc = ba_grow(s->poD, s->pocapD, nd))) return rc;
-    if ((rc = ba_grow(s->poB, s->pocapB, nb))) return rc;
-    if ((rc = ba_grow(s->poI, s->pocapI, (size_t)2 * n_problems + 4))) return rc;
-    double *d_pose = s->poD, *d_xw = d_pose + (((size_t)n_problems * 7 + 1) & ~(size_t)1), *d_obs = d_xw + (size_t)n * 3,
-           *d_info = d_obs + (size_t)n * 2;
-    uint8_t *d_fl = s->poB, *d_out = s->poB + n + 8;
-    int32_t *d_offs = s->poI, *d_ninl = s->poI + n_problems + 1;
-    /* inputs: packed in the pinned staging buffers in the device layout and sent as ONE copy per buffer (five copies
-       from pageable memory each cost a blocking bounce; Tracking calls this up to three times per frame) */
-    const size_t npose = ((size_t)n_problems * 7 + 1) & ~(size_t)1, nD_in = npose + (size_t)n * 6;
-    if ((rc = ba_grow_pinned(s->ppD, s->ppcapD, nD_in))) return rc;
-    if ((rc = ba_grow_pinned(s->ppI, s->ppcapI, (size_t)2 * n_problems + 4))) return rc;
-    if ((rc = ba_grow_pinned(s->ppB, s->ppcapB, std::max<size_t>((size_t)n, 1)))) return rc;
-    memcpy(s->ppD, poses, (size_t)n_problems * 56);
+    if ((rc = ba_grow(s->poB, s->pocapB, (size_t)n + 16))) return rc;
+    double *d_xw = s->poD, *d_obs = d_xw + (size_t)n * 3, *d_info = d_obs + (size_t)n * 2, *d_pose = s->poD + o_pose;
+    int32_t *d_offs = (int32_t *)(s->poD + o_offs), *d_ninl = (int32_t *)(s->poD + o_ninl);
+    uint8_t *d_fl = s->poB, *d_out = (uint8_t *)(s->poD + o_out);
+    if ((rc = ba_grow_pinned(s->ppD, s->ppcapD, nd))) return rc;
     if (n > 0) {
-        memcpy(s->ppD + npose, xw, (size_t)n * 24);
-        memcpy(s->ppD + npose + (size_t)n * 3, obs, (size_t)n * 16);
-        memcpy(s->ppD + npose + (size_t)n * 5, inv_sigma2, (size_t)n * 8);
+        memcpy(s->ppD, xw, (size_t)n * 24);
+        memcpy(s->ppD + (size_t)n * 3, obs, (size_t)n * 16);
+        memcpy(s->ppD + (size_t)n * 5, inv_sigma2, (size_t)n * 8);
     }
-    memcpy(s->ppI, offsets, (size_t)(n_problems + 1) * 4);
-    BCHK(hipMemcpyAsync(d_pose, s->ppD, nD_in * 8, hipMemcpyHostToDevice, s->stream));
-    BCHK(hipMemcpyAsync(d_offs, s->ppI, (size_t)(n_problems + 1) * 4, hipMemcpyHostToDevice, s->stream));
+    memcpy(s->ppD + o_offs, offsets, (size_t)(n_problems + 1) * 4);
+    memcpy(s->ppD + o_pose, poses, (size_t)n_problems * 56);
+    BCHK(hipMemcpyAsync(s->poD, s->ppD, (o_pose + npose) * 8, hipMemcpyHostToDevice, s->stream));
     int maxe = 0;
     for (int p = 0; p < n_problems; p++) maxe = std::max(maxe, offsets[p + 1] - offsets[p]);
     int lds_edges = 0;
@@ -4706,13 +4704,11 @@ extern "C" int ba_pose_optimization_batch(BASolver *s, double *poses, const doub
                        (const double *)d_obs, (const double *)d_info, d_fl, d_out, (const int32_t *)d_offs, fx, fy, cx, cy,
                        d_ninl, lds_edges, getenv("ORBSLAM_AMD_PO_TIMING") ? 1 : 0);
     BCHK(hipGetLastError());
-    BCHK(hipMemcpyAsync(s->ppD, d_pose, (size_t)n_problems * 56, hipMemcpyDeviceToHost, s->stream));
-    if (n > 0) BCHK(hipMemcpyAsync(s->ppB, d_out, (size_t)n, hipMemcpyDeviceToHost, s->stream));
-    BCHK(hipMemcpyAsync(s->ppI + n_problems + 1, d_ninl, (size_t)n_problems * 4, hipMemcpyDeviceToHost, s->stream));
+    BCHK(hipMemcpyAsync(s->ppD + o_pose, d_pose, (o_out + nout - o_pose) * 8, hipMemcpyDeviceToHost, s->stream));
     BCHK(hipStreamSynchronize(s->stream));
-    memcpy(poses, s->ppD, (size_t)n_problems * 56);
-    if (n > 0) memcpy(outlier, s->ppB, (size_t)n);
-    memcpy(n_inliers, s->ppI + n_problems + 1, (size_t)n_problems * 4);
+    memcpy(poses, s->ppD + o_pose, (size_t)n_problems * 56);
+    if (n > 0) memcpy(outlier, s->ppD + o_out, (size_t)n);
+    memcpy(n_inliers, s->ppD + o_ninl, (size_t)n_problems * 4);
     return ORB_OK;
 }
 
