@@ -4350,6 +4350,8 @@ struct POShared {
     double red[PO_T / 64][28];
     double pose[7], trial[7];
     double bc[4];
+    double cand_x[PO_T / 64][6], cand_t[PO_T / 64][7]; /* the next PO_T / 64 trial steps and poses, one per wavefront */
+    int cand_ok[PO_T / 64];
 };
 
 __device__ __forceinline__ void po_reduce(double *v, int nv, POShared &s, double *out) {
@@ -4588,15 +4590,43 @@ __global__ __launch_bounds__(PO_T) void k_pose_opt(double *pose7_all, const doub
             double rho = 0;
             int qmax = 0;
             do {
-                /* every thread solves the same 6x6 system redundantly (uniform, no broadcast needed) */
-                double x[6];
-                const bool ok2 = po_chol6_solve(H, lambda, b, x);
-                if (ok2) {
-                    se3_exp_mul_fast(x, pose, trial);
-                } else {
+                /* The trials of one iteration use lambda, lambda * ni, lambda * ni * 2 ni, ... -- known before the first one is
+                   evaluated -- and a rejected trial near convergence is the common case.  The 6 x 6 solve and the exponential
+                   map are a chain of ~300 dependent f64 operations that every wavefront used to run redundantly: now wavefront
+                   w runs it for the trial w steps ahead, so four trials cost one chain (same operations on the same values:
+                   the products lambda * ni * ... are formed in the sequential order). */
+                constexpr int PO_NW = PO_T / 64;
+                if ((qmax & (PO_NW - 1)) == 0) {
+                    const int wv = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+                    double lam_w = lambda, ni_w = ni;
+                    for (int m = 0; m < wv; m++) {
+                        lam_w *= ni_w;
+                        ni_w *= 2;
+                    }
+                    double xc[6], tc[7];
+                    const bool okc = po_chol6_solve(H, lam_w, b, xc);
+                    if (okc) {
+                        se3_exp_mul_fast(xc, pose, tc);
+                    } else {
 #pragma unroll
-                    for (int i = 0; i < 7; i++) trial[i] = pose[i];
+                        for (int i = 0; i < 7; i++) tc[i] = pose[i];
+                    }
+                    if ((tid & 63) == 0) {
+#pragma unroll
+                        for (int i = 0; i < 6; i++) s.cand_x[wv][i] = xc[i];
+#pragma unroll
+                        for (int i = 0; i < 7; i++) s.cand_t[wv][i] = tc[i];
+                        s.cand_ok[wv] = okc ? 1 : 0;
+                    }
+                    __syncthreads(); /* (the previous group's values were last read before the barriers of its trial's chi2 pass) */
                 }
+                double x[6];
+                const int cq = qmax & (PO_NW - 1);
+                const bool ok2 = s.cand_ok[cq] != 0;
+#pragma unroll
+                for (int i = 0; i < 6; i++) x[i] = s.cand_x[cq][i];
+#pragma unroll
+                for (int i = 0; i < 7; i++) trial[i] = s.cand_t[cq][i];
                 PO_TM(tS)
                 double tempChi = po_chi2(trial, xw, obs, info, fl, n, fx, fy, cx, cy, delta, s);
                 PO_TM(tC)
