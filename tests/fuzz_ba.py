@@ -21,7 +21,8 @@ def rel(a, b):
 # Tolerance carve-outs taken during a sweep, COUNTED (VERDICT r2 #1c): a window accepted although (a) its iteration count
 # differs from the oracle's (both converged to the same cost: the sign of the gain ratio at the minimum is rounding noise)
 # or (b) it misses 1e-5 but stays within a multiple of the oracle's own sensitivity to a 1e-13 perturbation of its input
-CARVEOUTS = {"iterations_differ_same_cost": 0, "unstable_problem_within_own_sensitivity": 0, "windows_checked": 0}
+CARVEOUTS = {"iterations_differ_same_cost": 0, "unstable_problem_within_own_sensitivity": 0, "cost_at_rounding_floor": 0,
+             "windows_checked": 0}
 
 
 def run(n_cfg=24, seed=3):
@@ -50,9 +51,15 @@ def run(n_cfg=24, seed=3):
         # different iteration count -- accepted when the costs agree to 1e-9
         same_its = got["iterations"] == ref["iterations"] or \
             abs(got["chi2_final"] - ref["chi2_final"]) <= 1e-9 * max(ref["chi2_final"], 1e-30)
+        # the cost of a NOISE-FREE window ends at rounding level (1e-21 .. 1e-27 from 1e+5): there its last digits are the
+        # summation order's, so the cost comparison has the same absolute floor as the batch sweep below (1e-18 of the
+        # initial cost); estimates, labels and iteration counts are still compared as everywhere
+        chi_tol = 1e-6 * max(ref["chi2_final"], 1e-30) + 1e-18 * ref["chi2_initial"]
         ok = (same_its and np.array_equal(got["outlier"], ref["outlier"]) and
               rel(got["points"], ref["points"]) < 1e-5 and rel(got["poses"][:, 4:], ref["poses"][:, 4:]) < 1e-5 and
-              abs(got["chi2_final"] - ref["chi2_final"]) <= 1e-6 * max(ref["chi2_final"], 1e-30))
+              abs(got["chi2_final"] - ref["chi2_final"]) <= chi_tol)
+        if ok and abs(got["chi2_final"] - ref["chi2_final"]) > 1e-6 * max(ref["chi2_final"], 1e-30):
+            CARVEOUTS["cost_at_rounding_floor"] += 1
         bad += 0 if ok else 1
         CARVEOUTS["windows_checked"] += 1
         if ok and got["iterations"] != ref["iterations"]:
